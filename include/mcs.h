@@ -1,0 +1,251 @@
+/* mcs.h -- C ABI of the MI355X-native per-particle transport path.
+ *
+ * Drop-in boundary: the `for i_prt in 1:n_pts_use` loop of the reference,
+ * /root/reference/src/main_loops.jl:228-292 (particle_loop + particle_finish!),
+ * batched into ONE call per (iteration, species, pcut).  The reference has no
+ * FFI for this path (it is pure Julia); INTEGRATION.md shows the `ccall` shim a
+ * maintainer would put in place of that loop.  All quantities are fp64 cgs, as
+ * in the reference after `ustrip`.
+ *
+ * Index conventions
+ *   grid tables : n_grid+2 entries, C index == Julia OffsetVector index 0:n_grid+1
+ *   zones       : Julia 1:n_grid  ->  C slot (i-1)
+ *   PSD bins    : 0-based in both
+ *   pcut/tcut/ion/iter numbers are passed 1-based (they enter the RNG seed formula
+ *   of src/particle_loop.jl:35-40 and index pₓ_esc_feb[i_ion, i_iter]).
+ *
+ * Error model: every entry point returns 0 on success, non-zero otherwise;
+ * mcs_last_error() returns the message (the reference's `error(...)` sites:
+ * src/particle_finish.jl:104, src/all_flux.jl:73-75, src/scattering.jl:52-53,
+ * src/prob_return.jl:134).  Warn-paths of the reference (@warn) are counters.
+ *
+ * Threading: one context per GPU; calls on one context must be serialised by
+ * the caller (the reference is single-threaded and not re-entrant).
+ */
+#ifndef MCS_H
+#define MCS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCS_ABI_VERSION 1
+
+/* ---- physical constants (cgs).  The reference takes them from Unitful /
+ * UnitfulGaussian / PhysicalConstants.CODATA2018 (src/MonteCarloScattering.jl:10-12,
+ * src/constants.jl:3); Project.toml has no lockfile, these are the CODATA-2018
+ * values those packages carry. */
+#define MCS_MP     1.67262192369e-24      /* proton mass [g] */
+#define MCS_ME     9.1093837015e-28       /* electron mass [g] */
+#define MCS_C      2.99792458e10          /* speed of light [cm/s] */
+#define MCS_QCGS   4.803204712570263e-10  /* elementary charge [esu] = 1.602176634e-19 C * c/10 */
+#define MCS_KB     1.380649e-16           /* Boltzmann [erg/K] */
+#define MCS_SIGMA_T 6.6524587321e-25      /* Thomson cross-section [cm^2] */
+#define MCS_B_CMB0 3.27e-6                /* src/constants.jl:10 [G] */
+/* src/constants.jl:30: rad_loss_fac = 4/3 c sigma_T / (c^3 me^2 8 pi)  [s^2/g^2] */
+#define MCS_RAD_LOSS_FAC ((4.0/3.0) * MCS_C * MCS_SIGMA_T / (MCS_C*MCS_C*MCS_C * MCS_ME*MCS_ME * 8.0 * 3.141592653589793))
+
+/* ---- compile-time constants of the path (src/parameters.jl, src/all_flux.jl:4,
+ * src/particle_finish.jl:5, src/particle_loop.jl:162, src/prob_return.jl:229) */
+#define MCS_PSD_MAX      200     /* parameters.jl:18 */
+#define MCS_NA_C         100     /* parameters.jl:11 */
+#define MCS_E_REL_PT     0.005   /* parameters.jl:32 */
+#define MCS_SPIKE_AWAY   1000.0  /* all_flux.jl:4, particle_finish.jl:5 */
+#define MCS_HELIX_CAP    10000   /* particle_loop.jl:162 */
+#define MCS_RETRO_XN_PER 10.0    /* prob_return.jl:229 */
+#define MCS_FLOOR        1.0e-99 /* particle_loop.jl:315-317, ion_init.jl:11-13 */
+
+/* i_reason codes (src/particle_loop.jl:138, src/particle_finish.jl:81-105) */
+#define MCS_REASON_SAVED      0  /* reached pcut, kept for next pcut (l_save) */
+#define MCS_REASON_DOWNSTREAM 1
+#define MCS_REASON_UPSTREAM   2  /* pmax or upstream FEB */
+#define MCS_REASON_AGE        3
+#define MCS_REASON_ZERO_E     4
+
+/* Scalars and flags handed to particle_loop at src/main_loops.jl:236-264. */
+typedef struct mcs_params {
+  int32_t abi_version;          /* = MCS_ABI_VERSION */
+  int32_t n_ions, n_grid, n_itrs;
+  int64_t n_pts_max;            /* MonteCarloScattering.jl:488; enters the seed formula */
+  int32_t i_grid_feb, i_shock;  /* MonteCarloScattering.jl:414,478 (Julia zone numbers) */
+  int32_t num_psd_mom_bins, num_psd_tht_bins;
+  int32_t psd_bins_per_dec_mom, psd_bins_per_dec_tht;
+  double  psd_cos_fine, psd_dcos, psd_tht_min, psd_mom_min;
+  double  gam0, beta0, u0, u2, bmag2;
+  double  pe_crit, game_crit, eta_mfp;
+  double  energy_transfer_frac;
+  double  feb_upstream, feb_downstream, x_grid_stop;
+  double  B_CMBz, age_max;
+  double  xn_per_fine, xn_per_coarse;
+  int32_t use_custom_epsB, do_rad_losses, do_retro, do_tcuts;
+  int32_t dont_DSA, dont_scatter, use_custom_frg;
+  int32_t track_thermal;        /* A9: bin non-injected crossings on the fly */
+} mcs_params;
+
+/* One particle population, struct-of-arrays, host side; element types follow the
+ * Julia arrays at src/MonteCarloScattering.jl:556-585 (Float64 / Int / Bool). */
+typedef struct mcs_soa {
+  double  *weight, *ptot_pf, *pb_pf, *x_PT_cm, *xn_per, *prp_x_cm, *acctime_sec, *phi_rad;
+  int64_t *grid, *tcut;
+  uint8_t *downstream, *inj;
+} mcs_soa;
+
+/* Offsets (in doubles) of every fp64 tally inside ONE flat buffer, so that a
+ * multi-GPU run merges all of them with a single sum-all-reduce.  Shapes and
+ * reset cadence: SURVEY.md section 8(a) "Tally arrays". */
+typedef struct mcs_layout {
+  int64_t psd;            /* [nmom+2][ntht+2][n_grid], momentum fastest (MonteCarloScattering.jl:519) */
+  int64_t therm_sf;       /* same shape as psd: non-injected crossings, shock frame   (A9) */
+  int64_t therm_pf;       /* same shape as psd: non-injected crossings, plasma frame of zone i (A9) */
+  int64_t esc_psd_up;     /* [201][201], ip fastest (MonteCarloScattering.jl:537) */
+  int64_t esc_psd_down;   /* [201][201] */
+  int64_t pxx_flux, pxz_flux, energy_flux;    /* [n_grid] */
+  int64_t esc_flux;       /* [n_ions] */
+  int64_t px_esc_feb, energy_esc_feb;         /* [n_ions][n_itrs], ion fastest */
+  int64_t esc_energy_eff, esc_num_eff;        /* [201][n_ions], ip fastest */
+  int64_t weight_coupled;                     /* [100][n_ions] */
+  int64_t spectra_coupled;                    /* [201][100][n_ions] */
+  int64_t spectra_sf, spectra_pf;             /* [201][n_grid] (2nd index = x_spec number) */
+  int64_t energy_transfer_pool, energy_recv_pool; /* [n_grid] */
+  int64_t scalars;        /* [4]: sumP_downstream, sumKEdensity_downstream, px_esc_upstream, energy_esc_upstream */
+  int64_t total;          /* number of doubles */
+  int64_t psd_stride_tht, psd_stride_zone;    /* nmom+2, (nmom+2)*(ntht+2) */
+} mcs_layout;
+
+/* int64 tallies / diagnostics, one flat buffer */
+enum {
+  MCS_I_NUM_CROSSINGS = 0,      /* [n_grid] src/all_flux.jl:254 */
+  /* the following are offsets from n_grid */
+  MCS_IC_STEPS_HELIX = 0,       /* passes of src/particle_loop.jl:154-499 */
+  MCS_IC_STEPS_RETRO,           /* passes of src/prob_return.jl:257-338 */
+  MCS_IC_HELIX_CAP,             /* particle_loop.jl:162 hits */
+  MCS_IC_PPERP_CLAMP,           /* particle_loop.jl:640-644 hits */
+  MCS_IC_PSP_CLAMP,             /* transformers.jl:562-568,592-598 hits */
+  MCS_IC_MOMBIN_CLAMP,          /* get_psd_bins.jl:29-36 hits */
+  MCS_IC_REASON0, MCS_IC_REASON1, MCS_IC_REASON2, MCS_IC_REASON3, MCS_IC_REASON4,
+  MCS_IC_TCUT_OVERRUN,          /* tcut index past n_tcuts (reference would throw BoundsError) */
+  MCS_IC_RNG_DRAWS,
+  MCS_IC_ZONE_FAIL,              /* src/all_flux.jl:73-75 would throw */
+  MCS_IC_COUNT
+};
+
+static inline int64_t mcs_i64_total(const mcs_params* p) { return (int64_t)p->n_grid + MCS_IC_COUNT; }
+
+static inline void mcs_tally_layout(const mcs_params* p, mcs_layout* L) {
+  const int64_t nm = p->num_psd_mom_bins + 2, nt = p->num_psd_tht_bins + 2, ng = p->n_grid;
+  const int64_t pm = MCS_PSD_MAX + 1;
+  int64_t o = 0;
+  L->psd_stride_tht = nm; L->psd_stride_zone = nm * nt;
+  L->psd = o;            o += nm * nt * ng;
+  L->therm_sf = o;       o += nm * nt * ng;
+  L->therm_pf = o;       o += nm * nt * ng;
+  L->esc_psd_up = o;     o += pm * pm;
+  L->esc_psd_down = o;   o += pm * pm;
+  L->pxx_flux = o;       o += ng;
+  L->pxz_flux = o;       o += ng;
+  L->energy_flux = o;    o += ng;
+  L->esc_flux = o;       o += p->n_ions;
+  L->px_esc_feb = o;     o += (int64_t)p->n_ions * p->n_itrs;
+  L->energy_esc_feb = o; o += (int64_t)p->n_ions * p->n_itrs;
+  L->esc_energy_eff = o; o += pm * p->n_ions;
+  L->esc_num_eff = o;    o += pm * p->n_ions;
+  L->weight_coupled = o; o += (int64_t)MCS_NA_C * p->n_ions;
+  L->spectra_coupled = o; o += pm * MCS_NA_C * p->n_ions;
+  L->spectra_sf = o;     o += pm * ng;
+  L->spectra_pf = o;     o += pm * ng;
+  L->energy_transfer_pool = o; o += ng;
+  L->energy_recv_pool = o;     o += ng;
+  L->scalars = o;        o += 4;
+  L->total = o;
+}
+
+typedef struct mcs_ctx mcs_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int         mcs_abi_version(void);
+/* non-inline export of mcs_tally_layout for FFI callers (Julia ccall, ctypes) */
+int         mcs_get_layout(const mcs_params* p, mcs_layout* out);
+const char* mcs_last_error(void);
+/* device: HIP device ordinal; stream: hipStream_t (NULL = default stream). */
+int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out);
+int mcs_destroy(mcs_ctx* ctx);
+int mcs_sync(mcs_ctx* ctx);
+
+/* Optional: make the context accumulate into caller-owned DEVICE buffers (e.g.
+ * torch tensors, so that torch.distributed can all-reduce them in place).
+ * Without this call the context allocates its own. */
+int mcs_bind_tallies(mcs_ctx* ctx, double* dev_f64, int64_t n_f64, int64_t* dev_i64, int64_t n_i64);
+double*  mcs_tallies_f64_devptr(mcs_ctx* ctx);
+int64_t* mcs_tallies_i64_devptr(mcs_ctx* ctx);
+
+/* ---- per-iteration / per-species inputs (host pointers) ----------------- */
+/* grid tables at src/main_loops.jl:255-260; n_entries = n_grid+2 */
+int mcs_set_grid(mcs_ctx* ctx, int n_entries, const double* x_grid_cm,
+                 const double* ux_sk, const double* uz_sk, const double* utot,
+                 const double* gam_sf, const double* gam_ef, const double* beta_ef,
+                 const double* btot, const double* theta);
+/* pcuts/tcuts/x_spec/inj_fracs/eps_target at src/main_loops.jl:244,259-262 */
+int mcs_set_cuts(mcs_ctx* ctx, int n_pcuts, const double* pcuts, int n_tcuts, const double* tcuts,
+                 int n_xspec, const double* x_spec, const double* inj_fracs /*[n_ions]*/,
+                 const double* eps_target /*[n_grid]*/);
+/* resets of src/main_loops.jl:59-86 (fluxes, weight_coupled := 1e-99; pools := 0; scalars := 1e-99) */
+int mcs_begin_iteration(mcs_ctx* ctx, int i_iter);
+/* src/main_loops.jl:97-121,164 + clear_psd! (src/ion_init.jl:1-16): psd/esc_psd := 1e-99,
+ * num_crossings/therm := 0, fluxes := 0 (quirk Q2), recv_pool := transfer_pool. */
+int mcs_begin_species(mcs_ctx* ctx, int i_iter, int i_ion, double aa, double zz,
+                      double pmax_cutoff, double density, double electron_weight_fac);
+/* analytic fast-push fluxes of init_pop/F_update! (src/initializers.jl:1054-1068,1156) */
+int mcs_set_fluxes(mcs_ctx* ctx, const double* pxx, const double* pxz, const double* energy);
+
+/* ---- population (device resident) --------------------------------------- */
+int mcs_pop_upload(mcs_ctx* ctx, int64_t n, const mcs_soa* host);
+int mcs_pop_download(mcs_ctx* ctx, int64_t n, mcs_soa* host);          /* current ("new") population */
+int mcs_saved_download(mcs_ctx* ctx, int64_t n, mcs_soa* host, uint8_t* l_save); /* *_saved arrays */
+int64_t mcs_pop_size(mcs_ctx* ctx);
+/* K3: fast-push part of init_pop (src/initializers.jl:1078-1131) +
+ * assign_particle_properties_to_population! (src/ion_init.jl:29-53), on device.
+ * ptot_pf_in/weight_in: host, n entries.  Population RNG: Philox key
+ * (i_iter-1)*n_ions+(i_ion-1) (src/main_loops.jl:120), draw j-1 = pitch of
+ * particle j, draw n_total+j-1 = phase of particle j (global j = j_offset+local). */
+int mcs_init_pop(mcs_ctx* ctx, int64_t n, int64_t j_offset, int64_t n_total,
+                 const double* ptot_pf_in, const double* weight_in,
+                 double x_start_cm, int i_grid_start, int relativistic, int fast_push);
+
+/* K1: the particle loop of one pcut over the resident population.
+ * i_prt_offset: global index of local particle 0 minus 1 (multi-GPU shards;
+ * the RNG key uses the global i_prt).  n_saved: particles that reached pcut. */
+int mcs_run_pcut(mcs_ctx* ctx, int i_pcut, int64_t i_prt_offset, int64_t* n_saved);
+/* K2: pcut_finalize/new_pcut (src/cuts.jl:34-124) on device: stable compaction
+ * of l_save and i_mult-fold replication with weight/i_mult. Returns new size. */
+int mcs_new_pcut(mcs_ctx* ctx, int64_t i_mult, int64_t* n_new);
+
+/* Host-buffer form of K1, the literal drop-in for the loop at main_loops.jl:228-292:
+ * upload `in`, run, download saved arrays + l_save. */
+int mcs_run_pcut_host(mcs_ctx* ctx, int i_pcut, int64_t n_pts_use, int64_t i_prt_offset,
+                      const mcs_soa* in, mcs_soa* saved_out, uint8_t* l_save, int64_t* n_saved);
+
+/* ---- tallies ------------------------------------------------------------ */
+int mcs_read_tallies(mcs_ctx* ctx, double* host_f64 /*layout.total*/, int64_t* host_i64 /*mcs_i64_total*/);
+int mcs_write_tallies(mcs_ctx* ctx, const double* host_f64, const int64_t* host_i64);
+
+/* ---- test / measurement hooks ------------------------------------------- */
+/* evaluate device math/RNG primitives (bit-parity tests): fn ids in mcs_fn */
+enum mcs_fn { MCS_FN_SIN = 0, MCS_FN_COS, MCS_FN_ASIN, MCS_FN_ACOS, MCS_FN_ATAN2, MCS_FN_LOG10,
+              MCS_FN_MOD2PI, MCS_FN_SQRT, MCS_FN_DIV, MCS_FN_HYPOT1, MCS_FN_UNIFORM };
+int mcs_eval_fn(mcs_ctx* ctx, int fn, int64_t n, const double* a, const double* b, double* out);
+/* per-particle end state of the last mcs_run_pcut (bit-parity tests): i_reason
+ * (0 = saved), helix_count, retro step count, final ptot_pf and x. Any pointer may be NULL. */
+int mcs_final_download(mcs_ctx* ctx, int64_t n, int32_t* reason, int32_t* helix_count,
+                       int32_t* retro_count, double* ptot_pf, double* x_PT_cm);
+/* kernel time [ms] of the last mcs_run_pcut, from HIP events on the context stream */
+double mcs_last_kernel_ms(mcs_ctx* ctx);
+/* launch geometry override: blocks (0 = auto), threads per block (0 = auto) */
+int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCS_H */

@@ -1,0 +1,537 @@
+// mcs_api.hip -- the C ABI of include/mcs.h over the gfx950 kernels.
+//
+// A context owns: device mirrors of the grid/cut tables, the resident particle
+// population (two SoA buffers: current and saved) and, unless the caller binds its
+// own (mcs_bind_tallies), the flat fp64/int64 tally buffers.  All work is queued
+// on ONE HIP stream; mcs_run_pcut is synchronous only for the 8-byte n_saved.
+// There is no CPU code path in this library.
+#include "mcs_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+size_t mcs_transport_smem_bytes(int n_grid);
+hipError_t mcs_launch_transport(const KArgs* a, int blocks, int threads, hipStream_t st);
+hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
+                               unsigned int* block_counts, unsigned long long* block_offsets,
+                               unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st);
+hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
+                               long long n_total, unsigned long long key, double m, double u, double x_start,
+                               int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
+                               hipStream_t st);
+hipError_t mcs_launch_fill(double* p, long long n, double v, hipStream_t st);
+hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStream_t st);
+hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b, double* out, hipStream_t st);
+}
+
+namespace {
+thread_local std::string g_err;
+
+int fail(const std::string& msg) { g_err = msg; return 1; }
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+struct PopBuf {
+  DevPop d{};
+  long long cap = 0;
+};
+}  // namespace
+
+struct mcs_ctx {
+  mcs_params P;
+  mcs_layout L;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // tables
+  double* d_tab = nullptr;     // 8 tables x (n_grid+2)
+  double* d_cuts = nullptr;    // pcuts | tcuts | x_spec | inj_fracs | eps_target
+  DevTables tb{};
+  std::vector<double> h_inj_fracs, h_pcuts, h_ux;
+  // tallies
+  double* d_T = nullptr; unsigned long long* d_I = nullptr; bool own_T = false, own_I = false;
+  // population
+  PopBuf cur, sav, spare;      // spare: target of the next split (buffers rotate, no per-pcut allocation)
+  uint8_t* d_lsave = nullptr; long long lsave_cap = 0;
+  long long n = 0;             // current population size
+  long long n_saved_last = 0;
+  // finals
+  int32_t *f_reason = nullptr, *f_helix = nullptr, *f_retro = nullptr; double *f_ptot = nullptr, *f_x = nullptr;
+  long long f_cap = 0;
+  // scan scratch
+  unsigned int* d_bcounts = nullptr; unsigned long long* d_boffs = nullptr; long long* d_src = nullptr; long long scan_cap = 0;
+  unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
+  // staging for init_pop
+  double* d_stage = nullptr; long long stage_cap = 0;
+  // species
+  int i_iter = 1, i_ion = 1;
+  double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
+  bool have_grid = false, have_cuts = false;
+  // launch
+  int blocks = 0, threads = 256;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  int n_cu = 256;
+};
+
+namespace {
+
+int pop_alloc(mcs_ctx* c, PopBuf& b, long long cap) {
+  if (cap <= b.cap) return 0;
+  double** f[8] = {&b.d.weight, &b.d.ptot_pf, &b.d.pb_pf, &b.d.x_PT_cm, &b.d.xn_per, &b.d.prp_x_cm, &b.d.acctime_sec, &b.d.phi_rad};
+  for (auto pp : f) { if (*pp) HIPCHK(hipFree(*pp)); *pp = nullptr; HIPCHK(hipMalloc((void**)pp, (size_t)cap * sizeof(double))); }
+  if (b.d.meta) HIPCHK(hipFree(b.d.meta));
+  HIPCHK(hipMalloc((void**)&b.d.meta, (size_t)cap * sizeof(uint32_t)));
+  b.cap = cap;
+  return 0;
+}
+void pop_free(PopBuf& b) {
+  double* f[8] = {b.d.weight, b.d.ptot_pf, b.d.pb_pf, b.d.x_PT_cm, b.d.xn_per, b.d.prp_x_cm, b.d.acctime_sec, b.d.phi_rad};
+  for (auto p : f) if (p) (void)hipFree(p);
+  if (b.d.meta) (void)hipFree(b.d.meta);
+  b = PopBuf{};
+}
+
+int ensure_capacity(mcs_ctx* c, long long n) {
+  // both buffers and every per-particle side array hold at least n entries
+  if (n > c->cur.cap || n > c->sav.cap) {
+    long long cap = n + n / 8 + 1024;
+    // growing must preserve the current population
+    if (c->n > 0 && c->cur.cap < cap) {
+      PopBuf nb;
+      if (pop_alloc(c, nb, cap)) return 1;
+      double* src[8] = {c->cur.d.weight, c->cur.d.ptot_pf, c->cur.d.pb_pf, c->cur.d.x_PT_cm, c->cur.d.xn_per, c->cur.d.prp_x_cm, c->cur.d.acctime_sec, c->cur.d.phi_rad};
+      double* dst[8] = {nb.d.weight, nb.d.ptot_pf, nb.d.pb_pf, nb.d.x_PT_cm, nb.d.xn_per, nb.d.prp_x_cm, nb.d.acctime_sec, nb.d.phi_rad};
+      for (int i = 0; i < 8; ++i) HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(nb.d.meta, c->cur.d.meta, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      pop_free(c->cur);
+      c->cur = nb;
+    } else if (pop_alloc(c, c->cur, cap)) return 1;
+    if (pop_alloc(c, c->sav, cap)) return 1;
+  }
+  if (n > c->lsave_cap) {
+    long long cap = n + n / 8 + 1024;
+    if (c->d_lsave) HIPCHK(hipFree(c->d_lsave));
+    HIPCHK(hipMalloc((void**)&c->d_lsave, (size_t)cap));
+    c->lsave_cap = cap;
+  }
+  if (n > c->f_cap) {
+    long long cap = n + n / 8 + 1024;
+    if (c->f_reason) { (void)hipFree(c->f_reason); (void)hipFree(c->f_helix); (void)hipFree(c->f_retro); (void)hipFree(c->f_ptot); (void)hipFree(c->f_x); }
+    HIPCHK(hipMalloc((void**)&c->f_reason, (size_t)cap * 4)); HIPCHK(hipMalloc((void**)&c->f_helix, (size_t)cap * 4));
+    HIPCHK(hipMalloc((void**)&c->f_retro, (size_t)cap * 4)); HIPCHK(hipMalloc((void**)&c->f_ptot, (size_t)cap * 8));
+    HIPCHK(hipMalloc((void**)&c->f_x, (size_t)cap * 8));
+    c->f_cap = cap;
+  }
+  if (n > c->scan_cap) {
+    long long cap = n + n / 8 + 1024;
+    long long nb = (cap + 1023) / 1024;
+    if (c->d_bcounts) { (void)hipFree(c->d_bcounts); (void)hipFree(c->d_boffs); (void)hipFree(c->d_src); }
+    HIPCHK(hipMalloc((void**)&c->d_bcounts, (size_t)nb * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&c->d_boffs, (size_t)nb * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&c->d_src, (size_t)cap * sizeof(long long)));
+    c->scan_cap = cap;
+  }
+  return 0;
+}
+
+int ensure_stage(mcs_ctx* c, long long n_doubles) {
+  if (n_doubles <= c->stage_cap) return 0;
+  if (c->d_stage) HIPCHK(hipFree(c->d_stage));
+  HIPCHK(hipMalloc((void**)&c->d_stage, (size_t)n_doubles * sizeof(double)));
+  c->stage_cap = n_doubles;
+  return 0;
+}
+
+int fill(mcs_ctx* c, long long off, long long n, double v) {
+  HIPCHK(mcs_launch_fill(c->d_T + off, n, v, c->stream));
+  return 0;
+}
+
+// host <-> packed device SoA
+int upload_soa(mcs_ctx* c, PopBuf& b, long long n, const mcs_soa* h) {
+  const double* src[8] = {h->weight, h->ptot_pf, h->pb_pf, h->x_PT_cm, h->xn_per, h->prp_x_cm, h->acctime_sec, h->phi_rad};
+  double* dst[8] = {b.d.weight, b.d.ptot_pf, b.d.pb_pf, b.d.x_PT_cm, b.d.xn_per, b.d.prp_x_cm, b.d.acctime_sec, b.d.phi_rad};
+  for (int i = 0; i < 8; ++i) HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  std::vector<uint32_t> meta((size_t)n);
+  for (long long k = 0; k < n; ++k) meta[k] = mcs_pack_meta((int)h->grid[k], (int)h->tcut[k], h->downstream[k] != 0, h->inj[k] != 0);
+  HIPCHK(hipMemcpyAsync(b.d.meta, meta.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int download_soa(mcs_ctx* c, const PopBuf& b, long long n, mcs_soa* h) {
+  double* dst[8] = {h->weight, h->ptot_pf, h->pb_pf, h->x_PT_cm, h->xn_per, h->prp_x_cm, h->acctime_sec, h->phi_rad};
+  const double* src[8] = {b.d.weight, b.d.ptot_pf, b.d.pb_pf, b.d.x_PT_cm, b.d.xn_per, b.d.prp_x_cm, b.d.acctime_sec, b.d.phi_rad};
+  for (int i = 0; i < 8; ++i) HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  std::vector<uint32_t> meta((size_t)n);
+  HIPCHK(hipMemcpyAsync(meta.data(), b.d.meta, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (long long k = 0; k < n; ++k) {
+    const uint32_t mm = meta[k];
+    h->grid[k] = (int64_t)(mm & 0xffffu); h->tcut[k] = (int64_t)((mm >> 16) & 0xffu);
+    h->downstream[k] = (uint8_t)((mm >> 24) & 1u); h->inj[k] = (uint8_t)((mm >> 25) & 1u);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcs_abi_version(void) { return MCS_ABI_VERSION; }
+const char* mcs_last_error(void) { return g_err.c_str(); }
+int mcs_get_layout(const mcs_params* p, mcs_layout* out) { mcs_tally_layout(p, out); return 0; }
+
+int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
+  if (!p || !out) return fail("mcs_create: null argument");
+  if (p->abi_version != MCS_ABI_VERSION) return fail("mcs_create: abi_version mismatch");
+  if (p->use_custom_frg) return fail("Use of custom f(r_g) not yet supported. Add functionality or use standard. (src/scattering.jl:52-53)");
+  if (!p->do_retro) return fail("Code not set up for analytical PRP calculations. (src/prob_return.jl:134)");
+  if (p->num_psd_mom_bins + 1 > MCS_PSD_MAX || p->num_psd_tht_bins + 1 > MCS_PSD_MAX) return fail("mcs_create: psd bins exceed psd_max (src/parameters.jl:18)");
+  if (p->n_grid < 1 || p->n_grid + 2 > 65535) return fail("mcs_create: n_grid out of range");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail("mcs_create: no HIP device visible; the transport path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail("mcs_create: device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  mcs_ctx* c = new mcs_ctx();
+  c->P = *p;
+  mcs_tally_layout(p, &c->L);
+  c->device = device;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->n_cu = prop.multiProcessorCount;
+  const int ne = p->n_grid + 2;
+  HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
+  c->own_T = c->own_I = true;
+  HIPCHK(hipMemsetAsync(c->d_T, 0, (size_t)c->L.total * sizeof(double), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_I, 0, (size_t)mcs_i64_total(p) * sizeof(unsigned long long), c->stream));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+int mcs_destroy(mcs_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
+  void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->own_T && c->d_T) (void)hipFree(c->d_T);
+  if (c->own_I && c->d_I) (void)hipFree(c->d_I);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int mcs_sync(mcs_ctx* c) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+
+int mcs_bind_tallies(mcs_ctx* c, double* dev_f64, int64_t n_f64, int64_t* dev_i64, int64_t n_i64) {
+  HIPCHK(hipSetDevice(c->device));
+  if (dev_f64) {
+    if (n_f64 < c->L.total) return fail("mcs_bind_tallies: f64 buffer smaller than layout.total");
+    if (c->own_T && c->d_T) (void)hipFree(c->d_T);
+    c->d_T = dev_f64; c->own_T = false;
+  }
+  if (dev_i64) {
+    if (n_i64 < mcs_i64_total(&c->P)) return fail("mcs_bind_tallies: i64 buffer too small");
+    if (c->own_I && c->d_I) (void)hipFree(c->d_I);
+    c->d_I = (unsigned long long*)dev_i64; c->own_I = false;
+  }
+  return 0;
+}
+double* mcs_tallies_f64_devptr(mcs_ctx* c) { return c->d_T; }
+int64_t* mcs_tallies_i64_devptr(mcs_ctx* c) { return (int64_t*)c->d_I; }
+
+int mcs_set_grid(mcs_ctx* c, int n_entries, const double* x_grid_cm, const double* ux, const double* uz, const double* utot,
+                 const double* gam_sf, const double* gam_ef, const double* beta_ef, const double* btot, const double* theta) {
+  HIPCHK(hipSetDevice(c->device));
+  const int ne = c->P.n_grid + 2;
+  if (n_entries != ne) return fail("mcs_set_grid: n_entries != n_grid+2");
+  for (int i = 0; i < ne; ++i) {
+    if (!(btot[i] > 0) || !(utot[i] != 0)) return fail("mcs_set_grid: btot must be > 0 and utot != 0 in every zone");
+    if (!std::isfinite(x_grid_cm[i])) return fail("mcs_set_grid: x_grid_cm must be finite (use +-1e30*rg0 sentinels)");
+  }
+  (void)beta_ef;  // passed by the reference (main_loops.jl:256) but never read by the path
+  const double* src[8] = {x_grid_cm, ux, uz, utot, gam_sf, gam_ef, btot, theta};
+  std::vector<double> h((size_t)8 * ne);
+  for (int t = 0; t < 8; ++t) std::memcpy(&h[(size_t)t * ne], src[t], (size_t)ne * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c->d_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->tb.x_grid = c->d_tab; c->tb.ux = c->d_tab + ne; c->tb.uz = c->d_tab + 2 * ne; c->tb.utot = c->d_tab + 3 * ne;
+  c->tb.gsf = c->d_tab + 4 * ne; c->tb.gef = c->d_tab + 5 * ne; c->tb.btot = c->d_tab + 6 * ne; c->tb.theta = c->d_tab + 7 * ne;
+  c->h_ux.assign(ux, ux + ne);
+  c->have_grid = true;
+  return 0;
+}
+
+int mcs_set_cuts(mcs_ctx* c, int n_pcuts, const double* pcuts, int n_tcuts, const double* tcuts, int n_xspec,
+                 const double* x_spec, const double* inj_fracs, const double* eps_target) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n_pcuts < 1 || n_pcuts > MCS_NA_C) return fail("momentum-cutoffs: parameter na_c smaller than desired number of pcuts.");
+  if (n_tcuts + 1 > MCS_NA_C) return fail("TCUTS: parameter na_c smaller than desired number of tcuts.");
+  if (n_tcuts > 255) return fail("mcs_set_cuts: n_tcuts > 255");
+  if (n_xspec > c->P.n_grid) return fail("mcs_set_cuts: n_xspec > n_grid");
+  const int ng = c->P.n_grid, ni = c->P.n_ions;
+  std::vector<double> h;
+  h.insert(h.end(), pcuts, pcuts + n_pcuts);
+  h.insert(h.end(), tcuts, tcuts + n_tcuts);
+  h.insert(h.end(), x_spec, x_spec + n_xspec);
+  h.insert(h.end(), inj_fracs, inj_fracs + ni);
+  h.insert(h.end(), eps_target, eps_target + ng);
+  if (c->d_cuts) HIPCHK(hipFree(c->d_cuts));
+  HIPCHK(hipMalloc((void**)&c->d_cuts, h.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->d_cuts, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double* q = c->d_cuts;
+  c->tb.pcuts = q; q += n_pcuts; c->tb.tcuts = q; q += n_tcuts; c->tb.x_spec = q; q += n_xspec;
+  c->tb.inj_fracs = q; q += ni; c->tb.eps_target = q;
+  c->tb.n_pcuts = n_pcuts; c->tb.n_tcuts = n_tcuts; c->tb.n_xspec = n_xspec;
+  c->h_pcuts.assign(pcuts, pcuts + n_pcuts);
+  c->h_inj_fracs.assign(inj_fracs, inj_fracs + ni);
+  c->have_cuts = true;
+  return 0;
+}
+
+int mcs_begin_iteration(mcs_ctx* c, int i_iter) {
+  HIPCHK(hipSetDevice(c->device));
+  if (i_iter < 1 || i_iter > c->P.n_itrs) return fail("mcs_begin_iteration: i_iter out of 1..n_itrs");
+  const mcs_params& P = c->P;
+  c->i_iter = i_iter;
+  if (fill(c, c->L.pxx_flux, P.n_grid, MCS_FLOOR) || fill(c, c->L.pxz_flux, P.n_grid, MCS_FLOOR) ||
+      fill(c, c->L.energy_flux, P.n_grid, MCS_FLOOR) || fill(c, c->L.weight_coupled, (long long)MCS_NA_C * P.n_ions, MCS_FLOOR) ||
+      fill(c, c->L.scalars, 4, MCS_FLOOR) || fill(c, c->L.energy_transfer_pool, P.n_grid, 0.0) ||
+      fill(c, c->L.energy_recv_pool, P.n_grid, 0.0))
+    return 1;
+  return 0;
+}
+
+int mcs_begin_species(mcs_ctx* c, int i_iter, int i_ion, double aa, double zz, double pmax_cutoff, double density, double ewf) {
+  HIPCHK(hipSetDevice(c->device));
+  const mcs_params& P = c->P;
+  if (i_ion < 1 || i_ion > P.n_ions) return fail("mcs_begin_species: i_ion out of 1..n_ions");
+  if (i_iter < 1 || i_iter > P.n_itrs) return fail("mcs_begin_species: i_iter out of 1..n_itrs");
+  if (!(aa > 0) || zz == 0) return fail("mcs_begin_species: aa must be > 0 and zz != 0");
+  c->i_iter = i_iter; c->i_ion = i_ion; c->aa = aa; c->zzq = zz * MCS_QCGS; c->m = aa * MCS_MP; c->mc = c->m * MCS_C;
+  c->pmax_cutoff = pmax_cutoff; c->density = density; c->ewf = ewf;
+  const long long npsd = c->L.psd_stride_zone * P.n_grid;
+  const long long pm = MCS_PSD_MAX + 1;
+  if (fill(c, c->L.psd, npsd, MCS_FLOOR) || fill(c, c->L.therm_sf, 2 * npsd, 0.0) ||
+      fill(c, c->L.esc_psd_up, 2 * pm * pm, MCS_FLOOR) || fill(c, c->L.pxx_flux, 3LL * P.n_grid, 0.0))
+    return 1;
+  HIPCHK(hipMemsetAsync(c->d_I + MCS_I_NUM_CROSSINGS, 0, (size_t)P.n_grid * sizeof(unsigned long long), c->stream));
+  HIPCHK(mcs_launch_copy(c->d_T + c->L.energy_recv_pool, c->d_T + c->L.energy_transfer_pool, P.n_grid, c->stream));
+  return 0;
+}
+
+int mcs_set_fluxes(mcs_ctx* c, const double* pxx, const double* pxz, const double* en) {
+  HIPCHK(hipSetDevice(c->device));
+  const int ng = c->P.n_grid;
+  HIPCHK(hipMemcpyAsync(c->d_T + c->L.pxx_flux, pxx, ng * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_T + c->L.pxz_flux, pxz, ng * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_T + c->L.energy_flux, en, ng * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mcs_pop_upload(mcs_ctx* c, int64_t n, const mcs_soa* host) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n < 0) return fail("mcs_pop_upload: n < 0");
+  for (int64_t k = 0; k < n; ++k) {
+    if (!(host->ptot_pf[k] > 0)) return fail("mcs_pop_upload: ptot_pf must be > 0 (zero-momentum particle: reference quirk G6)");
+    if (host->grid[k] < 0 || host->grid[k] > c->P.n_grid) return fail("mcs_pop_upload: grid index out of 0..n_grid");
+    if (host->tcut[k] < 1 || host->tcut[k] > 255) return fail("mcs_pop_upload: tcut out of range");
+  }
+  c->n = 0;
+  if (ensure_capacity(c, n)) return 1;
+  if (n > 0 && upload_soa(c, c->cur, n, host)) return 1;
+  c->n = n;
+  return 0;
+}
+int mcs_pop_download(mcs_ctx* c, int64_t n, mcs_soa* host) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n > c->n) return fail("mcs_pop_download: n exceeds the population size");
+  return download_soa(c, c->cur, n, host);
+}
+int mcs_saved_download(mcs_ctx* c, int64_t n, mcs_soa* host, uint8_t* l_save) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n > c->n) return fail("mcs_saved_download: n exceeds the population size");
+  if (host && download_soa(c, c->sav, n, host)) return 1;
+  if (l_save) { HIPCHK(hipMemcpyAsync(l_save, c->d_lsave, (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+  return 0;
+}
+int64_t mcs_pop_size(mcs_ctx* c) { return c->n; }
+
+int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const double* ptot_pf_in, const double* weight_in,
+                 double x_start_cm, int i_grid_start, int relativistic, int fast_push) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->have_grid) return fail("mcs_init_pop: call mcs_set_grid first");
+  if (n < 0 || i_grid_start < 0 || i_grid_start > c->P.n_grid) return fail("mcs_init_pop: bad arguments");
+  for (int64_t k = 0; k < n; ++k) if (!(ptot_pf_in[k] > 0)) return fail("mcs_init_pop: ptot_pf must be > 0 (reference quirk G6)");
+  c->n = 0;
+  if (ensure_capacity(c, n)) return 1;
+  if (ensure_stage(c, 2 * n + 2)) return 1;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(c->d_stage, ptot_pf_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage + n, weight_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned long long key = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_ions + (c->i_ion - 1));
+    HIPCHK(mcs_launch_init_pop(c->cur.d, c->d_stage, c->d_stage + n, n, j_offset, n_total, key, c->m, c->h_ux[i_grid_start],
+                               x_start_cm, i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->n = n;
+  return 0;
+}
+
+int mcs_set_launch(mcs_ctx* c, int blocks, int threads) {
+  if (threads != 0 && (threads % 64 != 0 || threads > 256)) return fail("mcs_set_launch: threads must be a multiple of 64, <= 256");
+  c->blocks = blocks; c->threads = threads ? threads : 256;
+  return 0;
+}
+
+int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->have_grid || !c->have_cuts) return fail("mcs_run_pcut: grid/cuts not set");
+  if (i_pcut < 1 || i_pcut > c->tb.n_pcuts) return fail("mcs_run_pcut: i_pcut out of range");
+  const long long n = c->n;
+  if (ensure_capacity(c, n)) return 1;
+  // main_loops.jl:184-197: l_save and the *_saved arrays start at zero
+  if (n > 0) {
+    HIPCHK(hipMemsetAsync(c->d_lsave, 0, (size_t)n, c->stream));
+    double* sv[8] = {c->sav.d.weight, c->sav.d.ptot_pf, c->sav.d.pb_pf, c->sav.d.x_PT_cm, c->sav.d.xn_per, c->sav.d.prp_x_cm, c->sav.d.acctime_sec, c->sav.d.phi_rad};
+    for (auto p : sv) HIPCHK(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->sav.d.meta, 0, (size_t)n * sizeof(uint32_t), c->stream));
+  }
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+
+  KArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.P = c->P; a.L = c->L; a.tb = c->tb; a.in = c->cur.d; a.sv = c->sav.d; a.l_save = c->d_lsave;
+  a.T = c->d_T; a.I = c->d_I;
+  a.aa = c->aa; a.zzq = c->zzq; a.m = c->m; a.mc = c->mc; a.pmax_cutoff = c->pmax_cutoff; a.density = c->density; a.ewf = c->ewf;
+  a.inj_frac = c->h_inj_fracs[c->i_ion - 1];
+  a.pcut = c->h_pcuts[i_pcut - 1];
+  a.pcut_prev = i_pcut > 1 ? c->h_pcuts[i_pcut - 2] : 0.0;
+  a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
+  a.n = n; a.i_prt_offset = i_prt_offset;
+  // iseed_mod - i_prt, src/particle_loop.jl:35-40
+  a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
+                                     (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
+                                     (long long)(i_pcut - 1) * c->P.n_pts_max);
+  a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
+  a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
+
+  const int threads = c->threads;
+  int blocks = c->blocks;
+  if (blocks <= 0) {
+    // persistent lanes: fill the chip, never launch more lanes than particles
+    const long long want = (n + threads - 1) / threads;
+    const long long full = (long long)c->n_cu * 4;     // 4 x 256-thread blocks per CU
+    blocks = (int)(want < full ? want : full);
+    if (blocks < 1) blocks = 1;
+  }
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  if (n > 0) HIPCHK(mcs_launch_transport(&a, blocks, threads, c->stream));
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  unsigned long long ns = 0;
+  HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_ms = ms;
+  c->n_saved_last = (long long)ns;
+  if (n_saved) *n_saved = (int64_t)ns;
+  return 0;
+}
+
+int mcs_new_pcut(mcs_ctx* c, int64_t i_mult, int64_t* n_new_out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (i_mult < 1) return fail("mcs_new_pcut: i_mult < 1");
+  const long long n = c->n, n_saved = c->n_saved_last;
+  const long long n_new = n_saved * i_mult;
+  // the split writes into the spare buffer, then the buffers rotate
+  if (pop_alloc(c, c->spare, n_new + n_new / 8 + 1024)) return 1;
+  if (ensure_capacity(c, n)) return 1;
+  HIPCHK(mcs_launch_new_pcut(c->d_lsave, n, c->sav.d, c->spare.d, i_mult, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src,
+                             n_saved, c->stream));
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->d_counters + 2, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n > 0 && (long long)total != n_saved) return fail("mcs_new_pcut: scan total != n_saved");
+  PopBuf t = c->cur; c->cur = c->spare; c->spare = t;
+  c->n = n_new;
+  if (ensure_capacity(c, n_new)) return 1;
+  if (n_new_out) *n_new_out = n_new;
+  return 0;
+}
+
+int mcs_run_pcut_host(mcs_ctx* c, int i_pcut, int64_t n_pts_use, int64_t i_prt_offset, const mcs_soa* in, mcs_soa* saved_out,
+                      uint8_t* l_save, int64_t* n_saved) {
+  if (mcs_pop_upload(c, n_pts_use, in)) return 1;
+  if (mcs_run_pcut(c, i_pcut, i_prt_offset, n_saved)) return 1;
+  return mcs_saved_download(c, n_pts_use, saved_out, l_save);
+}
+
+int mcs_read_tallies(mcs_ctx* c, double* host_f64, int64_t* host_i64) {
+  HIPCHK(hipSetDevice(c->device));
+  if (host_f64) HIPCHK(hipMemcpyAsync(host_f64, c->d_T, (size_t)c->L.total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (host_i64) HIPCHK(hipMemcpyAsync(host_i64, c->d_I, (size_t)mcs_i64_total(&c->P) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int mcs_write_tallies(mcs_ctx* c, const double* host_f64, const int64_t* host_i64) {
+  HIPCHK(hipSetDevice(c->device));
+  if (host_f64) HIPCHK(hipMemcpyAsync(c->d_T, host_f64, (size_t)c->L.total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (host_i64) HIPCHK(hipMemcpyAsync(c->d_I, host_i64, (size_t)mcs_i64_total(&c->P) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mcs_eval_fn(mcs_ctx* c, int fn, int64_t n, const double* a, const double* b, double* out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (ensure_stage(c, 3 * n + 3)) return 1;
+  double *da = c->d_stage, *db = c->d_stage + n, *dout = c->d_stage + 2 * n;
+  HIPCHK(hipMemcpyAsync(da, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(db, b ? b : a, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(mcs_launch_eval(fn, n, da, db, dout, c->stream));
+  HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mcs_final_download(mcs_ctx* c, int64_t n, int32_t* reason, int32_t* helix_count, int32_t* retro_count, double* ptot_pf,
+                       double* x_PT_cm) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n > c->f_cap) return fail("mcs_final_download: n too large");
+  if (reason) HIPCHK(hipMemcpyAsync(reason, c->f_reason, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (helix_count) HIPCHK(hipMemcpyAsync(helix_count, c->f_helix, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (retro_count) HIPCHK(hipMemcpyAsync(retro_count, c->f_retro, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (ptot_pf) HIPCHK(hipMemcpyAsync(ptot_pf, c->f_ptot, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (x_PT_cm) HIPCHK(hipMemcpyAsync(x_PT_cm, c->f_x, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+double mcs_last_kernel_ms(mcs_ctx* c) { return c->last_ms; }
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// mcs_device.h -- device-side data structures shared by the gfx950 kernels.
+#ifndef MCS_DEVICE_H
+#define MCS_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcs.h"
+
+// Device population, struct-of-arrays in HBM (coalesced: lane l touches element base+l).
+// The 12 per-particle fields of src/particle_loop.jl:48-59; the two indices and two
+// flags (Int64/Int64/Bool/Bool in the reference, 18 B) are packed into one 32-bit word:
+//   bits 0-15 grid zone, 16-23 tcut, 24 downstream, 25 inj.        68 B per particle.
+struct DevPop {
+  double *weight, *ptot_pf, *pb_pf, *x_PT_cm, *xn_per, *prp_x_cm, *acctime_sec, *phi_rad;
+  uint32_t* meta;
+};
+
+__host__ __device__ inline uint32_t mcs_pack_meta(int grid, int tcut, int downstream, int inj) {
+  return (uint32_t)(grid & 0xffff) | ((uint32_t)(tcut & 0xff) << 16) | ((uint32_t)(downstream & 1) << 24) |
+         ((uint32_t)(inj & 1) << 25);
+}
+
+struct DevTables {
+  const double *x_grid, *ux, *uz, *utot, *gsf, *gef, *btot, *theta;   // n_grid+2 entries each
+  const double *pcuts, *tcuts, *x_spec, *inj_fracs, *eps_target;
+  int n_pcuts, n_tcuts, n_xspec;
+};
+
+// Everything one launch of the transport kernel needs (passed by value: kernarg segment).
+struct KArgs {
+  mcs_params P;
+  mcs_layout L;
+  DevTables tb;
+  DevPop in, sv;
+  uint8_t* l_save;
+  double* T;                 // flat fp64 tallies (layout L)
+  unsigned long long* I;     // int64 tallies
+  // species / pcut scalars (src/main_loops.jl:97-105,205)
+  double aa, zzq, m, mc, pmax_cutoff, density, ewf, inj_frac;
+  double pcut, pcut_prev;
+  int i_iter, i_ion, i_pcut;
+  long long n;               // local population size
+  long long i_prt_offset;    // global i_prt of local particle 0, minus 1
+  unsigned long long seed_base;   // iseed_mod - i_prt   (src/particle_loop.jl:35-40)
+  unsigned long long* work_counter;   // next unclaimed particle
+  unsigned long long* n_saved;
+  int32_t *f_reason, *f_helix, *f_retro;
+  double *f_ptot, *f_x;
+};
+
+#endif

@@ -1,0 +1,183 @@
+"""Host driver: the iteration -> species -> pcut nest of the reference's
+`main_loops` (src/main_loops.jl:52-391) around the batched transport kernel.
+
+The reference calls `particle_loop` once per particle (main_loops.jl:228-292);
+here one backend call runs a whole pcut.  The population stays resident on the
+device between pcuts (K1 transport, K2 compaction+split, K3 initial fill);
+the host sees one 8-byte count per pcut.
+
+Multi-GPU (one process per GPU, torch.distributed; RCCL over xGMI when the
+backend is NCCL): particles are sharded in contiguous index ranges, the RNG key
+uses the *global* particle index so the histories do not depend on the number
+of GPUs, the per-pcut collective is an all-gather of `n_saved` (8 B per rank)
+and the per-species collective is ONE sum-all-reduce of the flat tally buffer.
+Baseline fills (1e-99 floors, analytic fast-push fluxes) live on rank 0 only so
+that the sum is the single-GPU result.
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import inputs
+from .inputs import Problem
+
+
+@dataclasses.dataclass
+class PcutStat:
+    i_iter: int
+    i_ion: int
+    i_pcut: int
+    n_pts_use: int          # global
+    n_saved: int            # global
+    i_mult: int
+    kernel_ms: float        # local kernel time (HIP events), nan for CPU backends
+    wall_ms: float
+
+
+@dataclasses.dataclass
+class RunResult:
+    tallies_f64: np.ndarray       # global (all-reduced) flat tallies after the last species
+    tallies_i64: np.ndarray
+    per_species: list             # [(i_iter, i_ion, f64, i64)] global tallies at each species end
+    stats: List[PcutStat]
+    steps_helix: int
+    steps_retro: int
+
+
+class Comm:
+    """Thin torch.distributed wrapper (None/1 rank -> no-ops)."""
+
+    def __init__(self, enabled: bool = False, device=None):
+        self.enabled = enabled
+        self.rank, self.world = 0, 1
+        self.device = device
+        if enabled:
+            import torch.distributed as dist
+            self.dist = dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def all_gather_int(self, v: int) -> List[int]:
+        if not self.enabled:
+            return [int(v)]
+        import torch
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    def all_reduce_sum_(self, tensor):
+        if self.enabled:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+        return tensor
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous, balanced index ranges; rank r gets [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[int] = None,
+        max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
+        verbose: bool = False) -> RunResult:
+    """Run `n_itrs` iterations of all species through all pcuts.
+
+    backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
+    run_pcut/new_pcut/pop_size/read_tallies/write_tallies/last_kernel_ms
+    (HipBackend in hip_backend.py; tests inject the CPU oracle's).
+    """
+    import torch
+
+    comm = comm or Comm(False)
+    cfg, P = prob.cfg, prob.params
+    n_itrs = n_itrs if n_itrs is not None else cfg.num_iterations
+    n_pcuts = len(prob.pcuts) if max_pcuts is None else min(max_pcuts, len(prob.pcuts))
+    L = backend.layout
+    stats: List[PcutStat] = []
+    per_species = []
+    # rank > 0 keeps only its local partial sums: everything it contributes is a delta
+    is_root = comm.rank == 0
+    G_f = G_i = None
+
+    for i_iter in range(1, n_itrs + 1):
+        backend.begin_iteration(i_iter)
+        if not is_root:
+            f, i = backend.read_tallies()
+            f[:] = 0.0
+            backend.write_tallies(f, i)
+        for i_ion, sp in enumerate(cfg.species, start=1):
+            pmax_cutoff = inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
+            inj = inputs.init_pop_host(prob, i_ion)
+            zz = abs(sp.zz) if cfg.abs_charge else sp.zz
+            ewf = 1.0 / cfg.species[-1].density if cfg.species[-1].density != 0 else float("inf")
+            backend.begin_species(i_iter, i_ion, sp.aa, zz, pmax_cutoff, sp.density, ewf)
+            if is_root:
+                backend.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+            if comm.world > 1:
+                f, i = backend.read_tallies()
+                if not is_root:   # per-species fills are baselines too
+                    for name in ("psd", "esc_psd_up", "esc_psd_down"):
+                        L.view(f, name)[...] = 0.0
+                if G_f is not None:  # ions' donated energy, merged at the previous species end
+                    L.view(f, "energy_recv_pool")[...] = L.view(G_f, "energy_transfer_pool")
+                backend.write_tallies(f, i)
+
+            n_total = inj.n_pts_use
+            lo, hi = shard_range(n_total, comm.rank, comm.world)
+            backend.init_pop(inj, lo, hi - lo, n_total)
+            offset = lo
+            p_pcut_hi = inputs.pcut_hi(cfg.EN_PCUT_HI, sp.mass)
+            n_use_global = n_total
+            for i_pcut in range(1, n_pcuts + 1):
+                t0 = time.perf_counter()
+                n_saved_local = backend.run_pcut(i_pcut, offset)
+                counts = comm.all_gather_int(n_saved_local)
+                n_saved = sum(counts)
+                wall = (time.perf_counter() - t0) * 1e3
+                # pcut_finalize (src/cuts.jl:100-124)
+                i_mult = 0
+                if n_saved > 0:
+                    n_target = cfg.N_PTS_PCUT if prob.pcuts[i_pcut - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI
+                    i_mult = max(n_target // n_saved, 1)         # new_pcut, src/cuts.jl:42
+                stats.append(PcutStat(i_iter, i_ion, i_pcut, n_use_global, n_saved, i_mult,
+                                      backend.last_kernel_ms(), wall))
+                if verbose and is_root:
+                    print(f"[iter {i_iter} ion {i_ion} pcut {i_pcut:2d}] n_use={n_use_global} n_saved={n_saved} "
+                          f"i_mult={i_mult} kernel={backend.last_kernel_ms():.2f} ms wall={wall:.1f} ms", flush=True)
+                if n_saved == 0:
+                    break
+                backend.new_pcut(i_mult)
+                offset = sum(counts[:comm.rank]) * i_mult
+                n_use_global = n_saved * i_mult
+
+            # species end: merge the partial tallies of all ranks (C1)
+            f, i = backend.read_tallies()
+            if comm.world > 1:
+                tf, ti = torch.from_numpy(f), torch.from_numpy(i)
+                if comm.device is not None and comm.device.type == "cuda":
+                    tf_d, ti_d = tf.to(comm.device), ti.to(comm.device)
+                    comm.all_reduce_sum_(tf_d); comm.all_reduce_sum_(ti_d)
+                    f, i = tf_d.cpu().numpy(), ti_d.cpu().numpy()
+                else:
+                    comm.all_reduce_sum_(tf); comm.all_reduce_sum_(ti)
+                G_f, G_i = f.copy(), i.copy()
+                if is_root:
+                    backend.write_tallies(G_f, G_i)
+                else:
+                    z = np.zeros_like(G_f)
+                    backend.write_tallies(z, np.zeros_like(G_i))
+            else:
+                G_f, G_i = f, i
+            per_species.append((i_iter, i_ion, G_f.copy(), G_i.copy()))
+            if on_species_end is not None:
+                on_species_end(i_iter, i_ion, G_f, G_i)
+
+    ng = P.n_grid
+    from .capi import IC
+    return RunResult(G_f, G_i, per_species, stats,
+                     int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]))

@@ -1,0 +1,155 @@
+"""The compute backend of the transport path: libmcs_hip.so (gfx950 kernels)
+through the C ABI of include/mcs.h.
+
+There is no other backend in this package and no fallback: if the library or a
+GPU is missing, construction fails with an error.  (Tests drive the same host
+driver with the CPU oracle by injecting a backend object defined under oracle/;
+the product never does.)
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+from . import capi
+from .capi import McsSoa, Population, c_double_p, c_int64_p, c_uint8_p, c_int32_p
+
+
+def _dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device: int = 0, stream: int = 0):
+        self.lib = capi.load_library()          # raises MissingNativeLibrary
+        if self.lib.mcs_abi_version() != capi.MCS_ABI_VERSION:
+            raise RuntimeError("libmcs_hip.so ABI version mismatch")
+        self.device = int(device)
+        self.stream = int(stream)
+        self.h = ct.c_void_p(None)
+        self._bound = None
+
+    # -- lifecycle
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libmcs_hip: " + self.lib.mcs_last_error().decode())
+
+    def create(self, prob):
+        self.prob = prob
+        self.P = prob.params
+        self.layout = capi.Layout(self.P)
+        self._chk(self.lib.mcs_create(ct.byref(self.P), self.device, ct.c_void_p(self.stream or None), ct.byref(self.h)))
+        tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in prob.grid_tables()]
+        self._chk(self.lib.mcs_set_grid(self.h, len(tabs[0]), *[_dp(t) for t in tabs]))
+        pc, tc, xs, inj, eps = (np.ascontiguousarray(a, dtype=np.float64) for a in
+                                (prob.pcuts, prob.tcuts, prob.x_spec, prob.inj_fracs, prob.eps_target))
+        self._chk(self.lib.mcs_set_cuts(self.h, len(pc), _dp(pc), len(tc), _dp(tc), len(xs), _dp(xs), _dp(inj), _dp(eps)))
+
+    def destroy(self):
+        if self.h:
+            self.lib.mcs_destroy(self.h)
+            self.h = ct.c_void_p(None)
+
+    def bind_torch_tallies(self, t_f64, t_i64):
+        """Accumulate into caller-owned torch CUDA tensors (for in-place all-reduce)."""
+        assert t_f64.is_cuda and t_f64.numel() >= self.layout.total
+        self._bound = (t_f64, t_i64)
+        self._chk(self.lib.mcs_bind_tallies(self.h, ct.c_void_p(t_f64.data_ptr()), t_f64.numel(),
+                                            ct.c_void_p(t_i64.data_ptr()), t_i64.numel()))
+
+    def set_launch(self, blocks: int = 0, threads: int = 0):
+        self._chk(self.lib.mcs_set_launch(self.h, blocks, threads))
+
+    # -- per iteration / species
+    def begin_iteration(self, i_iter):
+        self._chk(self.lib.mcs_begin_iteration(self.h, i_iter))
+
+    def begin_species(self, i_iter, i_ion, aa, zz, pmax_cutoff, density, ewf):
+        self._chk(self.lib.mcs_begin_species(self.h, i_iter, i_ion, aa, zz, pmax_cutoff, density, ewf))
+
+    def set_fluxes(self, pxx, pxz, en):
+        a, b, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (pxx, pxz, en))
+        self._chk(self.lib.mcs_set_fluxes(self.h, _dp(a), _dp(b), _dp(c)))
+
+    # -- population
+    def init_pop(self, inj, j_offset, n_local, n_total):
+        ptot = np.ascontiguousarray(inj.ptot_pf[j_offset:j_offset + n_local], dtype=np.float64)
+        w = np.ascontiguousarray(inj.weight[j_offset:j_offset + n_local], dtype=np.float64)
+        self._chk(self.lib.mcs_init_pop(self.h, n_local, j_offset, n_total, _dp(ptot), _dp(w), inj.x_start_cm,
+                                        inj.i_grid_start, int(inj.relativistic), int(inj.fast_push)))
+
+    def set_population(self, pop: Population):
+        s = pop.soa()
+        self._chk(self.lib.mcs_pop_upload(self.h, pop.n, ct.byref(s)))
+
+    def get_population(self) -> Population:
+        n = self.pop_size()
+        pop = Population(n)
+        s = pop.soa()
+        self._chk(self.lib.mcs_pop_download(self.h, n, ct.byref(s)))
+        return pop
+
+    def pop_size(self) -> int:
+        return int(self.lib.mcs_pop_size(self.h))
+
+    def run_pcut(self, i_pcut, i_prt_offset) -> int:
+        ns = ct.c_int64(0)
+        self._chk(self.lib.mcs_run_pcut(self.h, i_pcut, i_prt_offset, ct.byref(ns)))
+        return int(ns.value)
+
+    def run_pcut_host(self, i_pcut, pop: Population, i_prt_offset=0):
+        """The literal drop-in call (host buffers in, saved arrays out)."""
+        saved = Population(pop.n)
+        l_save = np.zeros(pop.n, dtype=np.uint8)
+        ns = ct.c_int64(0)
+        si, so = pop.soa(), saved.soa()
+        self._chk(self.lib.mcs_run_pcut_host(self.h, i_pcut, pop.n, i_prt_offset, ct.byref(si), ct.byref(so),
+                                             l_save.ctypes.data_as(c_uint8_p), ct.byref(ns)))
+        return saved, l_save, int(ns.value)
+
+    def get_saved(self):
+        n = self.pop_size()
+        saved = Population(n)
+        l_save = np.zeros(n, dtype=np.uint8)
+        s = saved.soa()
+        self._chk(self.lib.mcs_saved_download(self.h, n, ct.byref(s), l_save.ctypes.data_as(c_uint8_p)))
+        return saved, l_save
+
+    def finals(self):
+        n = self.pop_size()
+        reason = np.zeros(n, np.int32); helix = np.zeros(n, np.int32); retro = np.zeros(n, np.int32)
+        ptot = np.zeros(n); x = np.zeros(n)
+        self._chk(self.lib.mcs_final_download(self.h, n, reason.ctypes.data_as(c_int32_p), helix.ctypes.data_as(c_int32_p),
+                                              retro.ctypes.data_as(c_int32_p), _dp(ptot), _dp(x)))
+        return dict(reason=reason, helix=helix, retro=retro, ptot=ptot, x=x)
+
+    def new_pcut(self, i_mult) -> int:
+        nn = ct.c_int64(0)
+        self._chk(self.lib.mcs_new_pcut(self.h, i_mult, ct.byref(nn)))
+        return int(nn.value)
+
+    # -- tallies
+    def read_tallies(self):
+        f = np.zeros(self.layout.total)
+        i = np.zeros(self.layout.n_i64, dtype=np.int64)
+        self._chk(self.lib.mcs_read_tallies(self.h, _dp(f), i.ctypes.data_as(c_int64_p)))
+        return f, i
+
+    def write_tallies(self, f, i):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        i = np.ascontiguousarray(i, dtype=np.int64)
+        self._chk(self.lib.mcs_write_tallies(self.h, _dp(f), i.ctypes.data_as(c_int64_p)))
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.mcs_last_kernel_ms(self.h))
+
+    def eval_fn(self, name: str, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros_like(a)
+        self._chk(self.lib.mcs_eval_fn(self.h, capi.FN[name], len(a), _dp(a), _dp(b), _dp(out)))
+        return out

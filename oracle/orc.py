@@ -1,0 +1,190 @@
+"""ctypes wrapper of the CPU oracle (oracle/mcs_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+`OracleBackend` implements the same backend protocol as the HIP backend so the
+host driver (montecarloscattering.jl_amd/driver.py) can be run against either.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force: bool = False) -> None:
+    """Compile both oracle variants with the committed Makefile (gcc)."""
+    if force:
+        subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+
+
+def load(math: str = "det", capi=None):
+    path = os.path.join(HERE, f"libmcs_oracle_{math}.so")
+    if not os.path.exists(path):
+        build()
+    lib = ct.CDLL(path)
+    vp, i32, i64, dbl = ct.c_void_p, ct.c_int, ct.c_int64, ct.c_double
+    dp = ct.POINTER(ct.c_double)
+    i64p = ct.POINTER(ct.c_int64)
+    u8p = ct.POINTER(ct.c_uint8)
+    i32p = ct.POINTER(ct.c_int32)
+    u32p = ct.POINTER(ct.c_uint32)
+    soa_p = ct.POINTER(capi.McsSoa) if capi is not None else vp
+    par_p = ct.POINTER(capi.McsParams) if capi is not None else vp
+    sig = {
+        "orc_last_error": (ct.c_char_p, []),
+        "orc_math_mode": (ct.c_char_p, []),
+        "orc_create": (vp, [par_p]),
+        "orc_destroy": (None, [vp]),
+        "orc_set_grid": (i32, [vp, i32] + [dp] * 9),
+        "orc_set_cuts": (i32, [vp, i32, dp, i32, dp, i32, dp, dp, dp]),
+        "orc_begin_iteration": (i32, [vp, i32]),
+        "orc_begin_species": (i32, [vp, i32, i32, dbl, dbl, dbl, dbl, dbl]),
+        "orc_set_fluxes": (i32, [vp, dp, dp, dp]),
+        "orc_run_pcut": (i32, [vp, i32, i64, i64, soa_p, soa_p, u8p, i64p, i32]),
+        "orc_finals": (i32, [vp, i64, i32p, i32p, i32p, dp, dp]),
+        "orc_read_tallies": (i32, [vp, dp, i64p]),
+        "orc_write_tallies": (i32, [vp, dp, i64p]),
+        "orc_new_pcut": (i64, [i64, i64, u8p, soa_p, soa_p]),
+        "orc_init_pop": (i32, [vp, i64, i64, i64, dp, dp, dbl, i32, i32, i32, soa_p]),
+        "orc_philox_block": (None, [u32p, u32p, u32p]),
+        "orc_uniform": (dbl, [ct.c_uint64, ct.c_uint32, ct.c_uint64]),
+        "orc_eval_fn": (i32, [i32, i64, dp, dp, dp]),
+        "orc_scattering": (None, [vp, ct.c_uint64, dbl, dbl, dbl, dbl, dbl, dp, dp, dp, dp]),
+        "orc_transform_p_PS": (None, [dbl] * 11 + [dp]),
+        "orc_transform_p_PSP": (None, [vp] + [dbl] * 5 + [dp, dp, dp]),
+        "orc_bin_momentum": (i32, [vp, dbl]),
+        "orc_bin_angle": (i32, [vp, dbl, dbl]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ct.POINTER(ct.c_double))
+
+
+class OracleBackend:
+    """CPU oracle behind the driver's backend protocol."""
+
+    name = "oracle"
+
+    def __init__(self, capi, math: str = "det", nthreads: int = 1):
+        self.capi = capi
+        self.lib = load(math, capi)
+        self.math = math
+        self.nthreads = nthreads
+        self.h = None
+        self.pop = None
+        self.saved = None
+        self.l_save = None
+
+    # -- lifecycle
+    def create(self, prob):
+        self.prob = prob
+        self.P = prob.params
+        self.layout = self.capi.Layout(self.P)
+        self.h = self.lib.orc_create(ct.byref(self.P))
+        if not self.h:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+        tabs = [np.ascontiguousarray(t) for t in prob.grid_tables()]
+        self._chk(self.lib.orc_set_grid(self.h, len(tabs[0]), *[_dp(t) for t in tabs]))
+        self._keep = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                      (prob.pcuts, prob.tcuts, prob.x_spec, prob.inj_fracs, prob.eps_target)]
+        pc, tc, xs, inj, eps = self._keep
+        self._chk(self.lib.orc_set_cuts(self.h, len(pc), _dp(pc), len(tc), _dp(tc), len(xs), _dp(xs), _dp(inj), _dp(eps)))
+
+    def destroy(self):
+        if self.h:
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+
+    # -- per iteration / species
+    def begin_iteration(self, i_iter):
+        self._chk(self.lib.orc_begin_iteration(self.h, i_iter))
+
+    def begin_species(self, i_iter, i_ion, aa, zz, pmax_cutoff, density, ewf):
+        self._chk(self.lib.orc_begin_species(self.h, i_iter, i_ion, aa, zz, pmax_cutoff, density, ewf))
+
+    def set_fluxes(self, pxx, pxz, en):
+        a, b, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (pxx, pxz, en))
+        self._chk(self.lib.orc_set_fluxes(self.h, _dp(a), _dp(b), _dp(c)))
+
+    # -- population
+    def init_pop(self, inj, j_offset, n_local, n_total):
+        pop = self.capi.Population(n_local)
+        ptot = np.ascontiguousarray(inj.ptot_pf[j_offset:j_offset + n_local])
+        w = np.ascontiguousarray(inj.weight[j_offset:j_offset + n_local])
+        s = pop.soa()
+        self._chk(self.lib.orc_init_pop(self.h, n_local, j_offset, n_total, _dp(ptot), _dp(w), inj.x_start_cm,
+                                        inj.i_grid_start, int(inj.relativistic), int(inj.fast_push), ct.byref(s)))
+        self.pop = pop
+
+    def set_population(self, pop):
+        self.pop = pop
+
+    def get_population(self):
+        return self.pop
+
+    def pop_size(self):
+        return self.pop.n
+
+    def run_pcut(self, i_pcut, i_prt_offset):
+        n = self.pop.n
+        self.saved = self.capi.Population(n)
+        self.l_save = np.zeros(n, dtype=np.uint8)
+        ns = ct.c_int64(0)
+        si, so = self.pop.soa(), self.saved.soa()
+        self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, ct.byref(si), ct.byref(so),
+                                        self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), ct.byref(ns), self.nthreads))
+        return int(ns.value)
+
+    def get_saved(self):
+        return self.saved, self.l_save
+
+    def finals(self):
+        n = self.pop.n
+        reason = np.zeros(n, np.int32); helix = np.zeros(n, np.int32); retro = np.zeros(n, np.int32)
+        ptot = np.zeros(n); x = np.zeros(n)
+        i32p = ct.POINTER(ct.c_int32)
+        self._chk(self.lib.orc_finals(self.h, n, reason.ctypes.data_as(i32p), helix.ctypes.data_as(i32p),
+                                      retro.ctypes.data_as(i32p), _dp(ptot), _dp(x)))
+        return dict(reason=reason, helix=helix, retro=retro, ptot=ptot, x=x)
+
+    def new_pcut(self, i_mult):
+        n_saved = int(self.l_save.sum())
+        out = self.capi.Population(n_saved * i_mult)
+        ss, so = self.saved.soa(), out.soa()
+        n_new = self.lib.orc_new_pcut(self.pop.n, i_mult, self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)),
+                                      ct.byref(ss), ct.byref(so))
+        assert n_new == out.n
+        self.pop = out
+        return int(n_new)
+
+    # -- tallies
+    def read_tallies(self):
+        f = np.zeros(self.layout.total)
+        i = np.zeros(self.layout.n_i64, dtype=np.int64)
+        self._chk(self.lib.orc_read_tallies(self.h, _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64))))
+        return f, i
+
+    def write_tallies(self, f, i):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        i = np.ascontiguousarray(i, dtype=np.int64)
+        self._chk(self.lib.orc_write_tallies(self.h, _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64))))
+
+    def last_kernel_ms(self):
+        return float("nan")
