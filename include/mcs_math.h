@@ -33,6 +33,18 @@
 #pragma clang fp contract(off)
 #endif
 
+/* MCS_SC(c): a coefficient at its point of use.  On gfx950 the constant is built in a
+ * scalar register pair right where it is consumed (2 s_mov_b32, free on the scalar pipe)
+ * instead of being hoisted out of the particle loop into VGPRs: hipcc otherwise keeps
+ * ~150 VGPRs of polynomial coefficients live across the whole transport loop.  The value
+ * is unchanged, so results are bit-identical with and without it. */
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace mcsm { __device__ __forceinline__ double sc_(double c) { asm volatile("" : "+s"(c)); return c; } }
+#define MCS_SC(c) (::mcsm::sc_(c))
+#else
+#define MCS_SC(c) (c)
+#endif
+
 #define MCS_PI      MCS_PI_DD_0
 #define MCS_TWOPI   MCS_TWOPI_DD_0
 #define MCS_HALFPI  MCS_PIO2_DD_0
@@ -51,15 +63,15 @@ MCS_HD double from_bits_(uint64_t u) { union { double d; uint64_t u; } v; v.u = 
 
 /* ---- polynomial cores (Horner, fma) ------------------------------------ */
 MCS_HD double sin_core(double z) {
-  double p = MCS_SIN_5;
-  p = fma_(p, z, MCS_SIN_4); p = fma_(p, z, MCS_SIN_3); p = fma_(p, z, MCS_SIN_2);
-  p = fma_(p, z, MCS_SIN_1); p = fma_(p, z, MCS_SIN_0);
+  double p = MCS_SC(MCS_SIN_5);
+  p = fma_(p, z, MCS_SC(MCS_SIN_4)); p = fma_(p, z, MCS_SC(MCS_SIN_3)); p = fma_(p, z, MCS_SC(MCS_SIN_2));
+  p = fma_(p, z, MCS_SC(MCS_SIN_1)); p = fma_(p, z, MCS_SC(MCS_SIN_0));
   return p;
 }
 MCS_HD double cos_core(double z) {
-  double p = MCS_COS_5;
-  p = fma_(p, z, MCS_COS_4); p = fma_(p, z, MCS_COS_3); p = fma_(p, z, MCS_COS_2);
-  p = fma_(p, z, MCS_COS_1); p = fma_(p, z, MCS_COS_0);
+  double p = MCS_SC(MCS_COS_5);
+  p = fma_(p, z, MCS_SC(MCS_COS_4)); p = fma_(p, z, MCS_SC(MCS_COS_3)); p = fma_(p, z, MCS_SC(MCS_COS_2));
+  p = fma_(p, z, MCS_SC(MCS_COS_1)); p = fma_(p, z, MCS_SC(MCS_COS_0));
   return p;
 }
 /* sin and cos of a reduced argument |r| <= pi/4 */
@@ -72,9 +84,9 @@ MCS_HD double kcos(double r) {
 /* Cody-Waite reduction by pi/2; valid for |x| < ~1e5 (k*PIO2_0 exact). */
 MCS_HD double reduce_pio2(double x, int* n) {
   double k = __builtin_rint(x * MCS_TWO_OVER_PI);
-  double r = fma_(-k, MCS_PIO2_0, x);
-  r = fma_(-k, MCS_PIO2_1, r);
-  r = fma_(-k, MCS_PIO2_2, r);
+  double r = fma_(-k, MCS_SC(MCS_PIO2_0), x);
+  r = fma_(-k, MCS_SC(MCS_PIO2_1), r);
+  r = fma_(-k, MCS_SC(MCS_PIO2_2), r);
   *n = (int)k & 3;
   return r;
 }
@@ -95,8 +107,8 @@ MCS_HD double mod2pi(double x) {
   double r = x;
   if (!(r >= 0.0 && r < MCS_TWOPI)) {
     double k = __builtin_floor(x * MCS_INV_TWOPI);
-    r = fma_(-k, MCS_TWOPI_DD_0, x);
-    r = fma_(-k, MCS_TWOPI_DD_1, r);
+    r = fma_(-k, MCS_SC(MCS_TWOPI_DD_0), x);
+    r = fma_(-k, MCS_SC(MCS_TWOPI_DD_1), r);
     if (r < 0.0) r += MCS_TWOPI;
     if (r >= MCS_TWOPI) r -= MCS_TWOPI;
   }
@@ -104,11 +116,11 @@ MCS_HD double mod2pi(double x) {
 }
 
 MCS_HD double asin_core(double z) {
-  double p = MCS_ASIN_12;
-  p = fma_(p, z, MCS_ASIN_11); p = fma_(p, z, MCS_ASIN_10); p = fma_(p, z, MCS_ASIN_9);
-  p = fma_(p, z, MCS_ASIN_8);  p = fma_(p, z, MCS_ASIN_7);  p = fma_(p, z, MCS_ASIN_6);
-  p = fma_(p, z, MCS_ASIN_5);  p = fma_(p, z, MCS_ASIN_4);  p = fma_(p, z, MCS_ASIN_3);
-  p = fma_(p, z, MCS_ASIN_2);  p = fma_(p, z, MCS_ASIN_1);  p = fma_(p, z, MCS_ASIN_0);
+  double p = MCS_SC(MCS_ASIN_12);
+  p = fma_(p, z, MCS_SC(MCS_ASIN_11)); p = fma_(p, z, MCS_SC(MCS_ASIN_10)); p = fma_(p, z, MCS_SC(MCS_ASIN_9));
+  p = fma_(p, z, MCS_SC(MCS_ASIN_8));  p = fma_(p, z, MCS_SC(MCS_ASIN_7));  p = fma_(p, z, MCS_SC(MCS_ASIN_6));
+  p = fma_(p, z, MCS_SC(MCS_ASIN_5));  p = fma_(p, z, MCS_SC(MCS_ASIN_4));  p = fma_(p, z, MCS_SC(MCS_ASIN_3));
+  p = fma_(p, z, MCS_SC(MCS_ASIN_2));  p = fma_(p, z, MCS_SC(MCS_ASIN_1));  p = fma_(p, z, MCS_SC(MCS_ASIN_0));
   return p;
 }
 
@@ -119,7 +131,7 @@ MCS_HD double asin(double x) {
   double z = small ? x * x : (1.0 - ax) * 0.5;
   double s = small ? ax : sqrt_(z);
   double t = fma_(s * z, asin_core(z), s);            /* asin(s) */
-  double big = MCS_PIO2_DD_0 - (2.0 * t - MCS_PIO2_DD_1);
+  double big = MCS_SC(MCS_PIO2_DD_0) - (2.0 * t - MCS_PIO2_DD_1);
   return copysign_(small ? t : big, x);
 }
 
@@ -128,7 +140,7 @@ MCS_HD double acos(double x) {
   if (ax < 0.5) {
     double z = x * x;
     double t = fma_(x * z, asin_core(z), x);
-    return MCS_PIO2_DD_0 - (t - MCS_PIO2_DD_1);
+    return MCS_SC(MCS_PIO2_DD_0) - (t - MCS_PIO2_DD_1);
   }
   if (ax >= 1.0) return (x > 0.0) ? 0.0 : ((x < 0.0) ? MCS_PI : x);
   double z = (1.0 - ax) * 0.5;
@@ -138,11 +150,11 @@ MCS_HD double acos(double x) {
 }
 
 MCS_HD double atan_core(double z) {
-  double p = MCS_ATAN_10;
-  p = fma_(p, z, MCS_ATAN_9); p = fma_(p, z, MCS_ATAN_8); p = fma_(p, z, MCS_ATAN_7);
-  p = fma_(p, z, MCS_ATAN_6); p = fma_(p, z, MCS_ATAN_5); p = fma_(p, z, MCS_ATAN_4);
-  p = fma_(p, z, MCS_ATAN_3); p = fma_(p, z, MCS_ATAN_2); p = fma_(p, z, MCS_ATAN_1);
-  p = fma_(p, z, MCS_ATAN_0);
+  double p = MCS_SC(MCS_ATAN_10);
+  p = fma_(p, z, MCS_SC(MCS_ATAN_9)); p = fma_(p, z, MCS_SC(MCS_ATAN_8)); p = fma_(p, z, MCS_SC(MCS_ATAN_7));
+  p = fma_(p, z, MCS_SC(MCS_ATAN_6)); p = fma_(p, z, MCS_SC(MCS_ATAN_5)); p = fma_(p, z, MCS_SC(MCS_ATAN_4));
+  p = fma_(p, z, MCS_SC(MCS_ATAN_3)); p = fma_(p, z, MCS_SC(MCS_ATAN_2)); p = fma_(p, z, MCS_SC(MCS_ATAN_1));
+  p = fma_(p, z, MCS_SC(MCS_ATAN_0));
   return p;
 }
 
@@ -157,21 +169,21 @@ MCS_HD double atan2(double y, double x) {
     double a = mn / mx;
     double t = a, bh = 0.0, bl = 0.0;
     if (a > 0x1.a827999fcef32p-2 /* tan(pi/8) */) {
-      t = (a - 1.0) / (a + 1.0); bh = MCS_PIO4_DD_0; bl = MCS_PIO4_DD_1;
+      t = (a - 1.0) / (a + 1.0); bh = MCS_SC(MCS_PIO4_DD_0); bl = MCS_SC(MCS_PIO4_DD_1);
     }
     double z = t * t;
     double p = fma_(t * z, atan_core(z), t);
     r = bh + (p + bl);
-    if (ay > ax) r = MCS_PIO2_DD_0 - (r - MCS_PIO2_DD_1);
+    if (ay > ax) r = MCS_SC(MCS_PIO2_DD_0) - (r - MCS_PIO2_DD_1);
   }
-  if (x < 0.0 || (x == 0.0 && (bits_(x) >> 63))) r = MCS_PI_DD_0 - (r - MCS_PI_DD_1);
+  if (x < 0.0 || (x == 0.0 && (bits_(x) >> 63))) r = MCS_SC(MCS_PI_DD_0) - (r - MCS_PI_DD_1);
   return copysign_(r, y);
 }
 
 MCS_HD double log_core(double z) {
-  double p = MCS_LOG_6;
-  p = fma_(p, z, MCS_LOG_5); p = fma_(p, z, MCS_LOG_4); p = fma_(p, z, MCS_LOG_3);
-  p = fma_(p, z, MCS_LOG_2); p = fma_(p, z, MCS_LOG_1); p = fma_(p, z, MCS_LOG_0);
+  double p = MCS_SC(MCS_LOG_6);
+  p = fma_(p, z, MCS_SC(MCS_LOG_5)); p = fma_(p, z, MCS_SC(MCS_LOG_4)); p = fma_(p, z, MCS_SC(MCS_LOG_3));
+  p = fma_(p, z, MCS_SC(MCS_LOG_2)); p = fma_(p, z, MCS_SC(MCS_LOG_1)); p = fma_(p, z, MCS_SC(MCS_LOG_0));
   return p;
 }
 
@@ -187,8 +199,8 @@ MCS_HD double log10(double x) {
   double s2 = 2.0 * s;
   double lnm = fma_(s2 * z, log_core(z), s2);
   double de = (double)e;
-  double lo = fma_(lnm, MCS_INVLN10_DD_0, de * MCS_LOG10_2_1);
-  return fma_(de, MCS_LOG10_2_0, lo);
+  double lo = fma_(lnm, MCS_SC(MCS_INVLN10_DD_0), de * MCS_LOG10_2_1);
+  return fma_(de, MCS_SC(MCS_LOG10_2_0), lo);
 }
 
 /* hypot(1, t) as the path uses it (t = p/mc, 1e-6 .. 1e12): no scaling needed. */

@@ -157,7 +157,9 @@ def _as_dp(a: np.ndarray):
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmcs_hip.so")
+    # MCS_HIP_LIB: pick another build of the SAME library (kernel tuning variants)
+    name = os.environ.get("MCS_HIP_LIB", "libmcs_hip.so")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", name)
 
 
 class MissingNativeLibrary(RuntimeError):

@@ -14,8 +14,8 @@
 #include <vector>
 
 extern "C" {
-size_t mcs_transport_smem_bytes(int n_grid);
-hipError_t mcs_launch_transport(const KArgs* a, int blocks, int threads, hipStream_t st);
+size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
+hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
                                unsigned int* block_counts, unsigned long long* block_offsets,
                                unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st);
@@ -70,6 +70,8 @@ struct mcs_ctx {
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
   // staging for init_pop
   double* d_stage = nullptr; long long stage_cap = 0;
+  // launch constants: host copy (stable address for the async upload) and device copy
+  KArgs h_args; KArgs* d_args = nullptr;
   // species
   int i_iter = 1, i_ion = 1;
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
@@ -214,6 +216,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   const int ne = p->n_grid + 2;
   HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
   HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
@@ -233,7 +236,7 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage};
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
@@ -424,7 +427,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   }
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
 
-  KArgs a;
+  KArgs& a = c->h_args;
   std::memset(&a, 0, sizeof(a));
   a.P = c->P; a.L = c->L; a.tb = c->tb; a.in = c->cur.d; a.sv = c->sav.d; a.l_save = c->d_lsave;
   a.T = c->d_T; a.I = c->d_I;
@@ -450,8 +453,9 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
     blocks = (int)(want < full ? want : full);
     if (blocks < 1) blocks = 1;
   }
+  HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  if (n > 0) HIPCHK(mcs_launch_transport(&a, blocks, threads, c->stream));
+  if (n > 0) HIPCHK(mcs_launch_transport(c->d_args, c->P.n_grid, c->tb.n_tcuts, blocks, threads, c->stream));
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   unsigned long long ns = 0;
   HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));

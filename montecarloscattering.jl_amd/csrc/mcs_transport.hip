@@ -13,29 +13,55 @@
 //  * persistent lanes: a lane whose particle finished claims the next unclaimed
 //    particle (wave-aggregated atomic on one counter), so the 64 lanes of a wave
 //    stay busy although histories last 1 .. 10^4 steps;
-//  * the grid tables (9 x (n_grid+2) fp64) plus per-zone sin/cos(theta_B) and
-//    1/(qB) sit in LDS; the three flux vectors and num_crossings are staged in
-//    LDS (ds_add_f64) and flushed with one global atomic per entry per block;
-//    the 22 MB psd and the escape spectra take global_atomic_add_f64 directly;
+//  * the grid tables (n_grid+2 fp64 each) plus per-zone sin/cos(theta_B) and
+//    1/(qB), and the time cuts, sit in LDS; the three flux vectors and
+//    num_crossings are staged in LDS (ds_add_f64) and flushed with one global atomic
+//    per entry per block; the 22 MB psd and the escape spectra take
+//    global_atomic_add_f64 (no-return) directly;
+//  * the hot loop issues NO global load and NO scratch access: the vmcnt queue
+//    holds only no-return atomics, which nothing waits for;
+//  * launch constants are read through the constant address space (s_load);
 //  * RNG: Philox4x32-10 keyed by the reference's iseed_mod, counter = draw
-//    number; no RNG state in memory.
+//    number; no RNG state in memory;
 //  * no MFMA: scalar fp64 per-particle arithmetic.
 //
 // Numerics: every fp64 expression is evaluated in the same order as the CPU
 // oracle (which follows the Julia source), with include/mcs_math.h for the
 // transcendentals and -ffp-contract=off, so per-particle results are
 // bit-identical to the oracle; only the order of the atomic tally adds differs.
+// Values that are pure functions of unchanged inputs (per-zone sin/cos/1/(qB),
+// cos_max of the scattering cone) are cached, which does not change a bit.
 #include "mcs_device.h"
 #include "../../include/mcs_math.h"
 
 #pragma clang fp contract(off)
 
+#ifndef MCS_WAVES_PER_SIMD
+#define MCS_WAVES_PER_SIMD 2
+#endif
+// Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
+// calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
+#ifdef MCS_INLINE_COLD
+#define MCS_COLD __forceinline__
+#else
+#define MCS_COLD __noinline__
+#endif
+
+// Launch constants live in a per-context device buffer and are read through the
+// CONSTANT address space: uniform loads become s_load (scalar cache) and a field is
+// fetched where it is used, so cold-path fields do not occupy SGPRs in the hot loop.
+typedef const __attribute__((address_space(4))) KArgs CK;
+
 namespace {
 
-constexpr double PI_ = 3.141592653589793;
-constexpr double TWOPI_ = 6.283185307179586;
-constexpr double SIN_UL = 0x1.fffffffffffffp-1;
-constexpr double MP_ = MCS_MP, CC_ = MCS_C;
+// Literals are materialised in scalar registers at their point of use (MCS_SC, see
+// include/mcs_math.h) so that none of them is hoisted into a VGPR for the whole loop.
+#define PI_ MCS_SC(3.141592653589793)
+#define TWOPI_ MCS_SC(6.283185307179586)
+#define HALFPI_ MCS_SC(1.5707963267948966)   /* == 3.141592653589793 / 2 exactly */
+#define SIN_UL MCS_SC(0x1.fffffffffffffp-1)
+#define MP_ MCS_SC(MCS_MP)
+#define CC_ MCS_SC(MCS_C)
 
 // ---- Philox4x32-10 ------------------------------------------------------------
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -60,7 +86,7 @@ __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
 // draw of a block is kept in a register so that two consecutive draws cost one block.
 struct Rng {
   uint32_t k0, k1;
-  uint32_t n;        // draws so far (a history makes < 2^32 draws: <= 10^4 steps + retro)
+  uint32_t n;        // draws so far (a history makes < 2^32 draws)
   double spare;
   __device__ __forceinline__ double rand() {
     const uint32_t j = n++;
@@ -76,15 +102,20 @@ struct Rng {
 struct Lds {
   double *x, *ux, *uz, *ut, *gsf, *gef, *bt, *bsin, *bcos, *gd;   // n_grid+2 each
   double *fl;                                                   // 3*n_grid flux staging
+  double *tc;                                                   // n_tcuts time cuts
   int* nc;                                                      // n_grid crossings staging
 };
 
 // ---- particle state (registers) ---------------------------------------------------
+// The zone properties "of the current pass" (ux, uz, utot, gamma_sf, gamma_ef, sin/cos
+// theta_B; particle_loop.jl:195-204) are the LDS table entries of zone `ig3`, the zone the
+// particle was in when Code Block 3 last ran; they are re-read from LDS where needed.
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double gyro_denom, gyro_rad, gyro_rad_tot, gyro_period, t_step;
-  double ux, uz, ut, gsf, gef, bsin, bcos;
-  int i_grid, i_grid_old, helix, tcut, i_return, n_retro;
+  double tcut_next;              // tcuts[tcut-1] (LDS) or +inf
+  double cm_grt, cm_xn, cm_val;  // cache of cos_max for (gyro_rad_tot, xn_per) (scattering.jl:60)
+  int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
   bool downstream, inj;
 };
 
@@ -106,31 +137,38 @@ __device__ __forceinline__ void gadd_u64(unsigned long long* p, unsigned long lo
 __device__ __forceinline__ void ladd_i32(int* p, int v) {
   (void)__hip_atomic_fetch_add((lint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void cnt(const KArgs& a, int which, unsigned long long v = 1ull) {
-  gadd_u64(&a.I[a.P.n_grid + which], v);
+// Event counters are bumped in LDS (one ds_add_u32) and flushed once per block: a
+// per-particle global atomic on ONE address serialises at ~12 ns each (1e6 particles = 12 ms).
+__shared__ unsigned int g_ctr[MCS_IC_COUNT + 1];
+__shared__ double g_sc[8];   // [0..3] layout.scalars, [4] esc_flux, [5] px_esc_feb, [6] energy_esc_feb (this ion/iter)
+__device__ __forceinline__ void cnt(CK* a, int which, unsigned int v = 1u) {
+  (void)a;
+  (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int*)&g_ctr[which], v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void tadd(const KArgs& a, long long off, double v) { gadd_f64(&a.T[off], v); }
+__device__ __forceinline__ void sadd(int which, double v) { ladd_f64(&g_sc[which], v); }
+__device__ __forceinline__ void tadd(CK* a, long long off, double v) { gadd_f64(&a->T[off], v); }
 
 // src/get_psd_bins.jl:16-39
-__device__ __forceinline__ int bin_momentum(const KArgs& a, double ptot_sk) {
+__device__ __forceinline__ int bin_momentum(CK* a, double ptot_sk) {
   int bin;
-  if (ptot_sk < a.P.psd_mom_min) bin = 0;
-  else bin = (int)__builtin_trunc(mcsm::log10(ptot_sk / a.P.psd_mom_min) * a.P.psd_bins_per_dec_mom) + 1;
-  if (bin > a.P.num_psd_mom_bins) { cnt(a, MCS_IC_MOMBIN_CLAMP); bin = a.P.num_psd_mom_bins; }
+  if (ptot_sk < a->P.psd_mom_min) bin = 0;
+  else bin = (int)__builtin_trunc(mcsm::log10(ptot_sk / a->P.psd_mom_min) * a->P.psd_bins_per_dec_mom) + 1;
+  if (bin > a->P.num_psd_mom_bins) { cnt(a, MCS_IC_MOMBIN_CLAMP); bin = a->P.num_psd_mom_bins; }
   return bin;
 }
 // src/get_psd_bins.jl:73-97
-__device__ __forceinline__ int bin_angle(const KArgs& a, double px_sk, double ptot_sk) {
+__device__ __forceinline__ int bin_angle(CK* a, double px_sk, double ptot_sk) {
   if (ptot_sk == 0.0) return 0;
   const double p_cos = -px_sk / ptot_sk;
   int bin;
-  if (p_cos < a.P.psd_cos_fine) {
-    bin = a.P.num_psd_tht_bins - (int)__builtin_trunc((p_cos + 1) / a.P.psd_dcos);
+  if (p_cos < a->P.psd_cos_fine) {
+    bin = a->P.num_psd_tht_bins - (int)__builtin_trunc((p_cos + 1) / a->P.psd_dcos);
   } else {
     const double th = mcsm::acos(p_cos);
-    bin = th < a.P.psd_tht_min ? 0 : (int)__builtin_trunc(mcsm::log10(th / a.P.psd_tht_min) * a.P.psd_bins_per_dec_tht) + 1;
+    bin = th < a->P.psd_tht_min ? 0 : (int)__builtin_trunc(mcsm::log10(th / a->P.psd_tht_min) * a->P.psd_bins_per_dec_tht) + 1;
   }
-  return bin < a.P.num_psd_tht_bins ? bin : a.P.num_psd_tht_bins;
+  return bin < a->P.num_psd_tht_bins ? bin : a->P.num_psd_tht_bins;
 }
 
 // src/transformers.jl:440-476
@@ -139,7 +177,7 @@ __device__ __forceinline__ void transform_p_PS(double aa, double pb_pf, double p
                                                double& px, double& py, double& pz, double& gam_sk) {
   const double m = aa * MP_;
   const double mc = m * CC_;
-  const double phi_p = phi + PI_ / 2;
+  const double phi_p = phi + HALFPI_;
   double s, c;
   mcsm::sincos(phi_p, &s, &c);
   const double p_p_cos = p_perp * c;
@@ -152,66 +190,75 @@ __device__ __forceinline__ void transform_p_PS(double aa, double pb_pf, double p
   gam_sk = mcsm::hypot1(ptot_sk / mc);
 }
 
-// src/transformers.jl:523-607
-__device__ __forceinline__ void transform_p_PSP(const KArgs& a, Pt& p, double ux_o, double uz_o, double ut_o, double gsf_o,
-                                             double bcos_o, double bsin_o) {
-  const double aa = a.aa;
-  double phi_p = p.phi + PI_ / 2;
+// results of the rare momentum transforms, returned by value (registers)
+struct Mom { double ptot, pb, pperp, gam, phi; };
+
+// src/transformers.jl:523-607: zone io (old) -> zone in (new)
+__device__ MCS_COLD Mom transform_p_PSP(CK* a, Lds s, int io, int in, double r_pb, double r_pperp, double r_gam,
+                                            double r_phi) {
+  const double aa = a->aa;
+  const double ux_o = s.ux[io], uz_o = s.uz[io], ut_o = s.ut[io], gsf_o = s.gsf[io], bcos_o = s.bcos[io], bsin_o = s.bsin[io];
+  const double ux = s.ux[in], uz = s.uz[in], ut = s.ut[in], gsf = s.gsf[in], bcos = s.bcos[in], bsin = s.bsin[in];
+  double phi_p = r_phi + HALFPI_;
   const double m = aa * MP_;
   const double mc = m * CC_;
-  double s, c;
-  mcsm::sincos(phi_p, &s, &c);
-  const double p_p_cos = p.p_perp * c;
-  double fx = p.pb_pf * bcos_o - p_p_cos * bsin_o;
-  double fy = p.p_perp * s;
-  double fz = p.pb_pf * bsin_o + p_p_cos * bcos_o;
+  double sn, cs;
+  mcsm::sincos(phi_p, &sn, &cs);
+  const double p_p_cos = r_pperp * cs;
+  double fx = r_pb * bcos_o - p_p_cos * bsin_o;
+  double fy = r_pperp * sn;
+  double fz = r_pb * bsin_o + p_p_cos * bcos_o;
   double kx, ky, kz;
   {
     const double qx = ux_o / ut_o, qz = uz_o / ut_o;
-    kx = ((gsf_o - 1) * (qx * qx) + 1) * fx + (gsf_o - 1) * (ux_o * uz_o / (ut_o * ut_o)) * fz + gsf_o * p.gam_pf * m * ux_o;
+    kx = ((gsf_o - 1) * (qx * qx) + 1) * fx + (gsf_o - 1) * (ux_o * uz_o / (ut_o * ut_o)) * fz + gsf_o * r_gam * m * ux_o;
     ky = fy;
-    kz = (gsf_o - 1) * (ux_o * uz_o / (ut_o * ut_o)) * fx + ((gsf_o - 1) * (qz * qz) + 1) * fz + gsf_o * p.gam_pf * m * uz_o;
+    kz = (gsf_o - 1) * (ux_o * uz_o / (ut_o * ut_o)) * fx + ((gsf_o - 1) * (qz * qz) + 1) * fz + gsf_o * r_gam * m * uz_o;
   }
   const double ptot_sk = mcsm::norm3(kx, ky, kz);
-  double pb_sk = kx * p.bcos + kz * p.bsin;
+  const double pb_sk = kx * bcos + kz * bsin;
   if (ptot_sk < __builtin_fabs(pb_sk)) cnt(a, MCS_IC_PSP_CLAMP);   // the clamped shock-frame pair is never used again
   const double gam_sk = mcsm::hypot1(ptot_sk / mc);
   {
-    const double ux = p.ux, uz = p.uz, ut = p.ut, gsf = p.gsf;
     const double qx = ux / ut, qz = uz / ut;
     fx = ((gsf - 1) * (qx * qx) + 1) * kx + (gsf - 1) * (ux * uz / (ut * ut)) * kz - gsf * gam_sk * m * ux;
     fy = ky;
     fz = (gsf - 1) * (ux * uz / (ut * ut)) * kx + ((gsf - 1) * (qz * qz) + 1) * kz - gsf * gam_sk * m * uz;
   }
-  p.ptot_pf = mcsm::norm3(fx, fy, fz);
-  p.pb_pf = fx * p.bcos + fz * p.bsin;
-  if (p.ptot_pf < __builtin_fabs(p.pb_pf)) {
-    p.p_perp = 1.0e-6 * p.ptot_pf;
-    p.pb_pf = __builtin_copysign(__builtin_sqrt(p.ptot_pf * p.ptot_pf - p.p_perp * p.p_perp), p.pb_pf);
+  Mom r;
+  r.ptot = mcsm::norm3(fx, fy, fz);
+  r.pb = fx * bcos + fz * bsin;
+  if (r.ptot < __builtin_fabs(r.pb)) {
+    r.pperp = 1.0e-6 * r.ptot;
+    r.pb = __builtin_copysign(__builtin_sqrt(r.ptot * r.ptot - r.pperp * r.pperp), r.pb);
     cnt(a, MCS_IC_PSP_CLAMP);
   } else {
-    p.p_perp = __builtin_sqrt(p.ptot_pf * p.ptot_pf - p.pb_pf * p.pb_pf);
+    r.pperp = __builtin_sqrt(r.ptot * r.ptot - r.pb * r.pb);
   }
-  p.gam_pf = mcsm::hypot1(p.ptot_pf / mc);
-  phi_p = mcsm::atan2(fy, -fx * p.bsin + fz * p.bcos);
-  p.phi = phi_p - PI_ / 2;
+  r.gam = mcsm::hypot1(r.ptot / mc);
+  phi_p = mcsm::atan2(fy, -fx * bsin + fz * bcos);
+  r.phi = phi_p - HALFPI_;
+  return r;
 }
 
 // src/scattering.jl:29-101
-__device__ __forceinline__ void scattering(const KArgs& a, Rng& rng, Pt& p) {
-  const double aa = a.aa;
-  const double mc = aa * MP_ * CC_;
+__device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, double mc, double eta) {
   double grt;
-  if (aa < 1 && p.ptot_pf < a.P.pe_crit) {
-    grt = a.P.pe_crit * CC_ * p.gyro_denom;
-    p.gyro_period = TWOPI_ * a.P.game_crit * mc * p.gyro_denom;
+  if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
+    grt = a->P.pe_crit * CC_ * p.gyro_denom;
+    p.gyro_period = TWOPI_ * a->P.game_crit * mc * p.gyro_denom;
   } else {
     grt = p.ptot_pf * CC_ * p.gyro_denom;
     p.gyro_period = TWOPI_ * p.gam_pf * mc * p.gyro_denom;
   }
-  const double vp_tg = TWOPI_ * grt;
-  const double lam = a.P.eta_mfp * grt;
-  const double cos_max = mcsm::cos(__builtin_sqrt(6 * vp_tg / (p.xn_per * lam)));
+  // cos_max is a pure function of (grt, xn_per): recomputed only when either changed
+  if (grt != p.cm_grt || p.xn_per != p.cm_xn) {
+    const double vp_tg = TWOPI_ * grt;
+    const double lam = eta * grt;
+    p.cm_val = mcsm::cos(__builtin_sqrt(6 * vp_tg / (p.xn_per * lam)));
+    p.cm_grt = grt; p.cm_xn = p.xn_per;
+  }
+  const double cos_max = p.cm_val;
 
   const double cos_old = p.pb_pf / p.ptot_pf;
   const double sin_old = p.p_perp / p.ptot_pf;
@@ -226,18 +273,18 @@ __device__ __forceinline__ void scattering(const KArgs& a, Rng& rng, Pt& p) {
   const double sin_new = __builtin_sqrt(arg);
   p.pb_pf = p.ptot_pf * cos_new;
   p.p_perp = p.ptot_pf * sin_new;
-  const double phi_p_old = p.phi + PI_ / 2;
+  const double phi_p_old = p.phi + HALFPI_;
   double phi_p_new = phi_p_old;
   if (sin_new != 0) {
     double sd = s_ps * sin_d / sin_new;
     if (__builtin_fabs(sd) > SIN_UL) sd = __builtin_copysign(SIN_UL, sd);
     phi_p_new += mcsm::asin(sd);
   }
-  p.phi = phi_p_new - PI_ / 2;
+  p.phi = phi_p_new - HALFPI_;
 }
 
 // src/particle_loop.jl:639-650
-__device__ __forceinline__ double perpendicular_momentum(const KArgs& a, double ptot, double pb) {
+__device__ __forceinline__ double perpendicular_momentum(CK* a, double ptot, double pb) {
   if (ptot < __builtin_fabs(pb)) { cnt(a, MCS_IC_PPERP_CLAMP); return 1.0e-6 * ptot; }
   return __builtin_sqrt(ptot * ptot - pb * pb);
 }
@@ -249,91 +296,92 @@ __device__ __forceinline__ double radiation_loss(double B2, double pp, double dt
   return pp;
 }
 
-// src/cuts.jl:149-162
-__device__ __forceinline__ void tcut_track(const KArgs& a, int tcut_curr, double weight, double ptot_pf) {
-  const int ion = a.i_ion - 1;
-  tadd(a, a.L.weight_coupled + (tcut_curr - 1) + (long long)MCS_NA_C * ion, weight);
+// src/cuts.jl:149-162 plus the caller's `tcut_curr += 1` (particle_loop.jl:352-358, prob_return.jl:297-304)
+__device__ MCS_COLD void tcut_track(CK* a, int tcut_curr, double weight, double ptot_pf) {
+  const int ion = a->i_ion - 1;
+  tadd(a, a->L.weight_coupled + (tcut_curr - 1) + (long long)MCS_NA_C * ion, weight);
   const int i_pt = bin_momentum(a, ptot_pf);
-  tadd(a, a.L.spectra_coupled + i_pt + (long long)(MCS_PSD_MAX + 1) * ((tcut_curr - 1) + (long long)MCS_NA_C * ion), weight);
+  tadd(a, a->L.spectra_coupled + i_pt + (long long)(MCS_PSD_MAX + 1) * ((tcut_curr - 1) + (long long)MCS_NA_C * ion), weight);
+}
+__device__ __forceinline__ void tcut_check(CK* a, const Lds& s, Pt& p, int n_tcuts) {
+  if (p.tcut > n_tcuts) { cnt(a, MCS_IC_TCUT_OVERRUN); return; }   // D4
+  if (p.acctime >= p.tcut_next) {
+    tcut_track(a, p.tcut, p.weight, p.ptot_pf);
+    p.tcut += 1;
+    p.tcut_next = p.tcut <= n_tcuts ? s.tc[p.tcut - 1] : __builtin_inf();
+  }
 }
 
-// src/all_flux.jl:45-259 (all_flux!, calculate_x_spec_spectra!, F_stream!).  false: zone search failed.
-__device__ __forceinline__ bool all_flux(const KArgs& a, const Lds& s, Pt& p) {
-  const mcs_params& P = a.P;
-  p.i_grid_old = p.i_grid;
-  const int ne = P.n_grid + 2;
-  int found = -1;
-  if (p.x > p.x_old) {
-    for (int j = p.i_grid + 1; j < ne; ++j) if (s.x[j] > p.x) { found = j - 1; break; }
-  } else {
-    for (int j = p.i_grid; j >= 0; --j) if (s.x[j] <= p.x) { found = j; break; }
-  }
-  if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return false; }
-  p.i_grid = found;
-  const int n_xspec = a.tb.n_xspec;
-  if (p.i_grid == p.i_grid_old && p.i_grid > P.i_grid_feb && n_xspec == 0) return true;
-
-  const double aa = a.aa;
+// Tally part of all_flux! (src/all_flux.jl:84-161: transform, calculate_x_spec_spectra!,
+// F_stream!, FEB tracker), entered only when the zone changed (or i_grid <= i_grid_feb,
+// or x_spec detectors exist).  By-value arguments: nothing of the caller is forced to memory.
+__device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, double ptot_pf, double gam_pf,
+                                        double phi, double weight, double x, double x_old, int i_grid, int i_grid_old,
+                                        int ig3, bool inj) {
+  const auto& P = a->P;
+  const double aa = a->aa;
+  const double ux = s.ux[ig3], gsf = s.gsf[ig3], bcos = s.bcos[ig3], bsin = s.bsin[ig3];
   double ptot_sk, px, py, pz, gam_sk;
-  transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.ux, p.gsf, p.bcos, p.bsin, ptot_sk, px, py, pz, gam_sk);
+  transform_p_PS(aa, pb_pf, p_perp, gam_pf, phi, ux, gsf, bcos, bsin, ptot_sk, px, py, pz, gam_sk);
   const double m = aa * MP_;
   double pt_o_px_sk, abs_inv_vx;
   if (ptot_sk > __builtin_fabs(px * MCS_SPIKE_AWAY)) {
     pt_o_px_sk = MCS_SPIKE_AWAY;
-    abs_inv_vx = __builtin_fabs(MCS_SPIKE_AWAY / p.ux);
+    abs_inv_vx = __builtin_fabs(MCS_SPIKE_AWAY / ux);
   } else {
     pt_o_px_sk = ptot_sk / px;
     abs_inv_vx = __builtin_fabs(gam_sk * aa * MP_ / px);
   }
-  double pt_o_px_pf = __builtin_fabs(p.ptot_pf / p.pb_pf);
-  if (!(pt_o_px_pf < MCS_SPIKE_AWAY)) pt_o_px_pf = MCS_SPIKE_AWAY;
   double eadd;
-  if ((gam_sk - 1) > MCS_E_REL_PT) eadd = (gam_sk - 1) * m * (CC_ * CC_) * p.weight;
-  else eadd = ptot_sk * ptot_sk / (2 * m) * p.weight;
+  if ((gam_sk - 1) > MCS_E_REL_PT) eadd = (gam_sk - 1) * m * (CC_ * CC_) * weight;
+  else eadd = ptot_sk * ptot_sk / (2 * m) * weight;
 
+  const int n_xspec = a->tb.n_xspec;
   if (n_xspec > 0) {   // all_flux.jl:164-190
+    double pt_o_px_pf = __builtin_fabs(ptot_pf / pb_pf);
+    if (!(pt_o_px_pf < MCS_SPIKE_AWAY)) pt_o_px_pf = MCS_SPIKE_AWAY;
     const int i_pt = bin_momentum(a, ptot_sk);
-    const int i_pt_pf = bin_momentum(a, p.ptot_pf);
+    const int i_pt_pf = bin_momentum(a, ptot_pf);
     for (int i = 0; i < n_xspec; ++i) {
-      const double xs = a.tb.x_spec[i];
-      if ((p.x_old < xs && p.x >= xs) || (p.x <= xs && p.x_old > xs)) {
-        tadd(a, a.L.spectra_sf + i_pt + (long long)(MCS_PSD_MAX + 1) * i, p.weight * pt_o_px_sk);
-        const double Fw = __builtin_fabs(p.pb_pf / px) * (gam_sk / p.gam_pf);
-        tadd(a, a.L.spectra_pf + i_pt_pf + (long long)(MCS_PSD_MAX + 1) * i, p.weight * pt_o_px_pf * Fw);
+      const double xs = a->tb.x_spec[i];
+      if ((x_old < xs && x >= xs) || (x <= xs && x_old > xs)) {
+        tadd(a, a->L.spectra_sf + i_pt + (long long)(MCS_PSD_MAX + 1) * i, weight * pt_o_px_sk);
+        const double Fw = __builtin_fabs(pb_pf / px) * (gam_sk / gam_pf);
+        tadd(a, a->L.spectra_pf + i_pt_pf + (long long)(MCS_PSD_MAX + 1) * i, weight * pt_o_px_pf * Fw);
       }
     }
   }
 
   // F_stream! (all_flux.jl:197-259)
-  const bool down = p.x > p.x_old;
-  const int i_first = down ? p.i_grid_old + 1 : p.i_grid_old;
-  const int i_last = down ? p.i_grid : p.i_grid + 1;
+  const bool down = x > x_old;
+  const int i_first = down ? i_grid_old + 1 : i_grid_old;
+  const int i_last = down ? i_grid : i_grid + 1;
   const int step = down ? 1 : -1;
   const int sign_fac = down ? 1 : -1;
   const bool inj_check = !down;
   const int ng = P.n_grid;
   int i_pt = 0, jth = 0;
-  if (p.inj) { i_pt = bin_momentum(a, ptot_sk); jth = bin_angle(a, px, ptot_sk); }
-  const double f_pxx = sign_fac * px * p.weight * P.gam0 * P.u0;
-  const double f_pxz = __builtin_fabs(pz) * p.weight * P.gam0 * P.u0;
+  if (inj) { i_pt = bin_momentum(a, ptot_sk); jth = bin_angle(a, px, ptot_sk); }
+  const double f_pxx = sign_fac * px * weight * P.gam0 * P.u0;
+  const double f_pxz = __builtin_fabs(pz) * weight * P.gam0 * P.u0;
   const double f_en = sign_fac * eadd * P.gam0 * P.u0;
-  const double tw = p.weight * abs_inv_vx;
+  const double tw = weight * abs_inv_vx;
   int k_sf = 0, j_sf = 0;
   bool have_sf = false;
   for (int i = i_first; down ? i <= i_last : i >= i_last; i += step) {
-    if (inj_check && p.inj && i <= P.i_grid_feb) continue;
+    if (inj_check && inj && i <= P.i_grid_feb) continue;
     ladd_f64(&s.fl[i - 1], f_pxx);
     ladd_f64(&s.fl[ng + i - 1], f_pxz);
     ladd_f64(&s.fl[2 * ng + i - 1], f_en);
-    if (p.inj) {
-      tadd(a, a.L.psd + i_pt + a.L.psd_stride_tht * jth + a.L.psd_stride_zone * (long long)(i - 1), tw);
+    if (inj) {
+      tadd(a, a->L.psd + i_pt + a->L.psd_stride_tht * jth + a->L.psd_stride_zone * (long long)(i - 1), tw);
     } else {
       if (P.track_thermal) {   // A9: bin the thermal crossing instead of appending to a list
         if (!have_sf) { k_sf = bin_momentum(a, ptot_sk); j_sf = bin_angle(a, px, ptot_sk); have_sf = true; }
-        tadd(a, a.L.therm_sf + k_sf + a.L.psd_stride_tht * j_sf + a.L.psd_stride_zone * (long long)(i - 1), tw);
+        tadd(a, a->L.therm_sf + k_sf + a->L.psd_stride_tht * j_sf + a->L.psd_stride_zone * (long long)(i - 1), tw);
         const double gam = s.gsf[i];
         const double beta = s.ux[i] / CC_;
-        const double E0 = a.m * CC_ * CC_;
+        const double E0 = a->m * CC_ * CC_;
         const double pc = ptot_sk * CC_;
         const double etot = __builtin_sqrt(pc * pc + E0 * E0);
         double px_Xf = gam * (px - beta * etot / CC_);
@@ -341,116 +389,144 @@ __device__ __forceinline__ bool all_flux(const KArgs& a, const Lds& s, Pt& p) {
         if (__builtin_fabs(px_Xf) > pt_Xf) px_Xf = __builtin_copysign(pt_Xf, px_Xf);
         const int k_pf = bin_momentum(a, pt_Xf);
         const int j_pf = bin_angle(a, px_Xf, pt_Xf);
-        tadd(a, a.L.therm_pf + k_pf + a.L.psd_stride_tht * j_pf + a.L.psd_stride_zone * (long long)(i - 1), tw);
+        tadd(a, a->L.therm_pf + k_pf + a->L.psd_stride_tht * j_pf + a->L.psd_stride_zone * (long long)(i - 1), tw);
       }
       ladd_i32(&s.nc[i - 1], 1);
     }
   }
-  if (p.inj && p.x < P.feb_upstream && p.x_old >= P.feb_upstream) {
-    tadd(a, a.L.scalars + 3, eadd * P.gam0 * P.u0);
-    tadd(a, a.L.scalars + 2, -(px * p.weight * P.gam0 * P.u0));
+  if (inj && x < P.feb_upstream && x_old >= P.feb_upstream) {
+    sadd(3, eadd * P.gam0 * P.u0);
+    sadd(2, -(px * weight * P.gam0 * P.u0));
   }
-  return true;
 }
 
+// state that retro_time reads and writes, passed and returned by value (registers)
+struct Retro {
+  double ptot, pb, pperp, gam, phi, gyro_denom, acctime, tcut_next;
+  int tcut, n_retro;
+  uint32_t rng_n; double rng_spare;
+  bool lose_pt;
+};
+
 // src/prob_return.jl:217-344 (with D1: the scattered pitch is kept)
-__device__ __forceinline__ void retro_time(const KArgs& a, const Lds& s, Rng& rng, Pt& p, bool& lose_pt) {
-  const mcs_params& P = a.P;
+__device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double weight, uint32_t k0, uint32_t k1) {
+  const auto& P = a->P;
   const int ng = P.n_grid;
-  const double aa = a.aa;
+  const double aa = a->aa;
+  Rng rng; rng.k0 = k0; rng.k1 = k1; rng.n = r.rng_n; rng.spare = r.rng_spare;
   const double xn_per = MCS_RETRO_XN_PER;
   const double phi_step = TWOPI_ / xn_per;
-  const double t_step_fac = TWOPI_ * aa * MP_ * CC_ * p.gyro_denom / xn_per;
+  const double t_step_fac = TWOPI_ * aa * MP_ * CC_ * r.gyro_denom / xn_per;
   const double ux_sk = -s.ux[ng];
   const double gsf = s.gsf[ng];
   const double gef = s.gef[ng];
   double B = s.bt[ng];
-  if (P.use_custom_epsB) B *= __builtin_sqrt(P.x_grid_stop / p.prp);
+  if (P.use_custom_epsB) B *= __builtin_sqrt(P.x_grid_stop / prp);
   const double bcos = s.bcos[ng], bsin = s.bsin[ng];
   const double B_CMB_loc = P.B_CMBz * gef;
   double B2_tot = B * B + B_CMB_loc * B_CMB_loc;
-  lose_pt = false;
-  double x_PT = p.prp;
-  p.phi = rng.rand() * TWOPI_;
-  const int n_tcuts = a.tb.n_tcuts;
+  r.lose_pt = false;
+  double x_PT = prp;
+  r.phi = rng.rand() * TWOPI_;
+  const int n_tcuts = a->tb.n_tcuts;
   const double mc = aa * MP_ * CC_;
   while (true) {
-    ++p.n_retro;
+    ++r.n_retro;
     const double x_PT_old = x_PT;
-    const double phi_old = p.phi;
+    const double phi_old = r.phi;
     if (P.use_custom_epsB) {
       B = s.bt[ng] * __builtin_sqrt(P.x_grid_stop / x_PT);
       B2_tot = B * B + B_CMB_loc * B_CMB_loc;
-      p.gyro_denom = 1 / (a.zzq * B);
+      r.gyro_denom = 1 / (a->zzq * B);
     }
-    const double gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-    p.phi = mcsm::mod2pi(phi_old + phi_step);
-    const double t_step = t_step_fac * p.gam_pf;
-    const double x_move = p.pb_pf * t_step_fac / (aa * MP_);
+    const double gyro_rad = r.pperp * CC_ * r.gyro_denom;
+    r.phi = mcsm::mod2pi(phi_old + phi_step);
+    const double t_step = t_step_fac * r.gam;
+    const double x_move = r.pb * t_step_fac / (aa * MP_);
     double gyr = 0.0;
-    if (bsin != 0.0) gyr = gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+    if (bsin != 0.0) gyr = gyro_rad * bsin * (mcsm::cos(r.phi) - mcsm::cos(phi_old));
     x_PT = x_PT_old + gsf * (x_move * bcos - gyr + ux_sk * t_step);
-    p.acctime += t_step * gef;
+    r.acctime += t_step * gef;
     if (P.do_tcuts) {
-      if (p.tcut > n_tcuts) cnt(a, MCS_IC_TCUT_OVERRUN);
-      else if (p.acctime >= a.tb.tcuts[p.tcut - 1]) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
+      if (r.tcut > n_tcuts) cnt(a, MCS_IC_TCUT_OVERRUN);   // D4
+      else if (r.acctime >= r.tcut_next) {
+        tcut_track(a, r.tcut, weight, r.ptot);
+        r.tcut += 1;
+        r.tcut_next = r.tcut <= n_tcuts ? s.tc[r.tcut - 1] : __builtin_inf();
+      }
     }
-    p.phi = TWOPI_ * rng.rand();
-    const double ptot_old = p.ptot_pf;
-    p.pb_pf = (2 * rng.rand() - 1) * p.ptot_pf;
-    double arg = p.ptot_pf * p.ptot_pf - p.pb_pf * p.pb_pf;
+    r.phi = TWOPI_ * rng.rand();
+    const double ptot_old = r.ptot;
+    r.pb = (2 * rng.rand() - 1) * r.ptot;
+    double arg = r.ptot * r.ptot - r.pb * r.pb;
     if (arg < 0) arg = 0;
-    p.p_perp = __builtin_sqrt(arg);
-    const double cos_new = p.pb_pf / ptot_old;
-    const double sin_new = p.p_perp / ptot_old;
-    if (P.do_rad_losses && aa < 1) p.ptot_pf = radiation_loss(B2_tot, p.ptot_pf, t_step);
-    if (p.ptot_pf <= 0) {
-      p.ptot_pf = MCS_FLOOR; p.gam_pf = 1.0; lose_pt = true;
+    r.pperp = __builtin_sqrt(arg);
+    const double cos_new = r.pb / ptot_old;
+    const double sin_new = r.pperp / ptot_old;
+    if (P.do_rad_losses && aa < 1) r.ptot = radiation_loss(B2_tot, r.ptot, t_step);
+    if (r.ptot <= 0) {
+      r.ptot = MCS_FLOOR; r.gam = 1.0; r.lose_pt = true;
       break;
     } else {
-      p.pb_pf = p.ptot_pf * cos_new;
-      p.p_perp = p.ptot_pf * sin_new;
-      p.gam_pf = mcsm::hypot1(p.ptot_pf / mc);
+      r.pb = r.ptot * cos_new;
+      r.pperp = r.ptot * sin_new;
+      r.gam = mcsm::hypot1(r.ptot / mc);
     }
-    if (x_PT < p.prp) break;
+    if (x_PT < prp) break;
   }
+  r.rng_n = rng.n; r.rng_spare = rng.spare;
+  return r;
 }
 
+// hot-loop constants, fetched once per wave (SGPRs)
+struct Hot {
+  double aa, m, mc, zzq, pcut, pmax_cutoff, feb_up, feb_down, age_max, x_grid_stop, u2, eta, xn_fine, xn_coarse, inj_frac;
+  int n_grid, i_grid_feb, n_tcuts, n_xspec;
+  bool custom_epsB, etf, dont_scatter, rad_losses, do_tcuts, dont_DSA;
+};
+
 // src/prob_return.jl:36-173
-__device__ __forceinline__ void prob_return(const KArgs& a, const Lds& s, Rng& rng, Pt& p, bool& lose_pt) {
-  const mcs_params& P = a.P;
-  const double aa = a.aa;
+__device__ __forceinline__ void prob_return(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, bool& lose_pt) {
+  const auto& P = a->P;
+  const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
   p.i_return = 2;
   lose_pt = false;
-  if (p.x < P.x_grid_stop) {
-  } else if (p.x_old < P.x_grid_stop && P.x_grid_stop <= p.x) {
+  if (p.x < x_grid_stop) {
+  } else if (p.x_old < x_grid_stop && x_grid_stop <= p.x) {
     double gyro_tmp;
-    if (P.use_custom_epsB && p.x > P.x_grid_stop) gyro_tmp = __builtin_sqrt(P.x_grid_stop / p.x); else gyro_tmp = 1.0;
+    if (h.custom_epsB && p.x > x_grid_stop) gyro_tmp = __builtin_sqrt(x_grid_stop / p.x); else gyro_tmp = 1.0;
     const double grt = p.ptot_pf * CC_ * gyro_tmp / (MCS_QCGS * P.bmag2);
-    const double L_diff = P.eta_mfp / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * P.u2);
+    const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
     p.prp = p.x + 3 * L_diff;
   } else if (p.x_old < p.prp && p.x >= p.prp) {
     const double vt = p.ptot_pf / (p.gam_pf * aa * MP_);
-    const double q = (vt - P.u2) / (vt + P.u2);
+    const double q = (vt - u2) / (vt + u2);
     const double prob_ret = q * q;
-    if (vt < P.u2 || rng.rand() > prob_ret) {
+    if (vt < u2 || rng.rand() > prob_ret) {
       p.i_return = 0;
     } else {
       p.i_return = 1;
-      retro_time(a, s, rng, p, lose_pt);
+      Retro r;
+      r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+      r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = p.tcut_next; r.tcut = p.tcut;
+      r.n_retro = p.n_retro; r.rng_n = rng.n; r.rng_spare = rng.spare; r.lose_pt = false;
+      r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
+      p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut_next = r.tcut_next; p.tcut = r.tcut;
+      p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
       if (lose_pt) p.i_return = 0;
       p.x = p.prp;
     }
   } else {
-    if (aa < 1 && p.ptot_pf < a.pcut_prev && p.helix % 1000 == 0) {
+    if (aa < 1 && p.ptot_pf < a->pcut_prev && p.helix % 1000 == 0) {
       const double grt = p.ptot_pf * CC_ * p.gyro_denom;
-      const double L_diff = P.eta_mfp / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * P.u2);
+      const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
       if (p.x > 2.0e3 * L_diff) {
         p.prp = 0.8 * p.x;
       } else {
-        const double r = a.pcut_prev / p.ptot_pf;
+        const double r = a->pcut_prev / p.ptot_pf;
         const double r2 = r * r;
-        const double alt = P.x_grid_stop + L_diff * (r2 * r2 * r);
+        const double alt = x_grid_stop + L_diff * (r2 * r2 * r);
         p.prp = p.prp < alt ? p.prp : alt;
       }
     }
@@ -458,120 +534,121 @@ __device__ __forceinline__ void prob_return(const KArgs& a, const Lds& s, Rng& r
 }
 
 // src/particle_loop.jl:652-723
-__device__ __forceinline__ void do_energy_transfer(const KArgs& a, Pt& p) {
-  const mcs_params& P = a.P;
-  const int i_start = p.i_grid_old;
-  const int i_stop = p.i_grid < P.i_shock ? p.i_grid : P.i_shock;
+__device__ MCS_COLD Mom do_energy_transfer(CK* a, int i_grid, int i_grid_old, double weight, Mom r) {
+  const auto& P = a->P;
+  const int i_start = i_grid_old;
+  const int i_stop = i_grid < P.i_shock ? i_grid : P.i_shock;
   bool scale = false;
-  const double m = a.aa * MP_;
+  const double m = a->aa * MP_;
   const double E0 = m * (CC_ * CC_);
-  double gam_f = p.gam_pf;
+  double gam_f = r.gam;
   double eps_max = -1e300, recv_max = 0.0;
   for (int i = i_start + 1; i <= i_stop; ++i) {
     if (i < 1 || i > P.n_grid) continue;
-    const double e = a.tb.eps_target[i - 1];
+    const double e = a->tb.eps_target[i - 1];
     if (e > eps_max) eps_max = e;
-    const double r = a.T[a.L.energy_recv_pool + (i - 1)];
-    if (r > recv_max) recv_max = r;
+    const double v = a->T[a->L.energy_recv_pool + (i - 1)];
+    if (v > recv_max) recv_max = v;
   }
-  if (a.aa >= 1 && eps_max > 0) {
-    const double gam_i = mcsm::hypot1(p.ptot_pf / a.mc);
-    const double eps_stop = a.tb.eps_target[i_stop - 1];
-    const double eps_start = i_start >= 1 ? a.tb.eps_target[i_start - 1] : 0.0;
+  if (a->aa >= 1 && eps_max > 0) {
+    const double gam_i = mcsm::hypot1(r.ptot / a->mc);
+    const double eps_stop = a->tb.eps_target[i_stop - 1];
+    const double eps_start = i_start >= 1 ? a->tb.eps_target[i_start - 1] : 0.0;
     gam_f = 1 + (gam_i - 1) * (1 - eps_stop) / (1 - eps_start);
     int n_split = 0;
-    for (int i = i_start + 1; i <= i_stop; ++i) if (a.tb.eps_target[i - 1] > 0) ++n_split;
-    const double inc = (gam_i - gam_f) * E0 * p.weight / n_split;
+    for (int i = i_start + 1; i <= i_stop; ++i) if (a->tb.eps_target[i - 1] > 0) ++n_split;
+    const double inc = (gam_i - gam_f) * E0 * weight / n_split;
     for (int i = i_start + 1; i <= i_stop; ++i)
-      if (a.tb.eps_target[i - 1] > 0) tadd(a, a.L.energy_transfer_pool + (i - 1), inc);
+      if (a->tb.eps_target[i - 1] > 0) tadd(a, a->L.energy_transfer_pool + (i - 1), inc);
     scale = true;
   } else if (recv_max > 0) {
     double sum = 0.0;
-    for (int i = i_start + 1; i <= i_stop; ++i) sum += a.T[a.L.energy_recv_pool + (i - 1)];
-    const double e_tr = sum * a.ewf;
-    const double gam_i = mcsm::hypot1(p.ptot_pf / a.mc);
+    for (int i = i_start + 1; i <= i_stop; ++i) sum += a->T[a->L.energy_recv_pool + (i - 1)];
+    const double e_tr = sum * a->ewf;
+    const double gam_i = mcsm::hypot1(r.ptot / a->mc);
     gam_f = gam_i + e_tr / E0;
     scale = true;
   }
   if (scale) {
-    const double ptot_f = a.mc * __builtin_sqrt(gam_f * gam_f - 1);
-    const double sf = ptot_f / p.ptot_pf;
-    p.pb_pf *= sf;
-    p.p_perp *= sf;
-    p.ptot_pf = ptot_f;
-    p.gam_pf = gam_f;
+    const double ptot_f = a->mc * __builtin_sqrt(gam_f * gam_f - 1);
+    const double sf = ptot_f / r.ptot;
+    r.pb *= sf;
+    r.pperp *= sf;
+    r.ptot = ptot_f;
+    r.gam = gam_f;
   }
+  return r;
 }
 
-// src/particle_finish.jl:46-107 (with D2)
-__device__ __forceinline__ void particle_finish(const KArgs& a, const Pt& p, int i_reason) {
-  const double aa = a.aa;
+// src/particle_finish.jl:46-107 (with D2).  Zone properties of zone ig3.
+__device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_pf, double p_perp, double gam_pf,
+                                             double phi, double weight, int ig3) {
+  const double aa = a->aa;
   const double m = aa * MP_;
   const double E0 = m * (CC_ * CC_);
   double ptot_sk, px, py, pz, gam_sk;
-  transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.ux, p.gsf, p.bcos, p.bsin, ptot_sk, px, py, pz, gam_sk);
+  transform_p_PS(aa, pb_pf, p_perp, gam_pf, phi, s.ux[ig3], s.gsf[ig3], s.bcos[ig3], s.bsin[ig3], ptot_sk, px, py, pz, gam_sk);
   const int ip = bin_momentum(a, ptot_sk);
   const int jth = bin_angle(a, px, ptot_sk);
   double wf;
   if (ptot_sk > __builtin_fabs(MCS_SPIKE_AWAY * px)) wf = gam_sk * m * MCS_SPIKE_AWAY / ptot_sk;
   else wf = gam_sk * (m / __builtin_fabs(px));
   const long long pm = MCS_PSD_MAX + 1;
-  const int ion = a.i_ion - 1, iter = a.i_iter - 1;
+  const int ion = a->i_ion - 1;
   if (i_reason == 1) {
-    tadd(a, a.L.esc_psd_down + ip + pm * jth, p.weight * wf);
+    tadd(a, a->L.esc_psd_down + ip + pm * jth, weight * wf);
   } else if (i_reason == 2) {
-    tadd(a, a.L.esc_flux + ion, p.weight);
-    tadd(a, a.L.esc_psd_up + ip + pm * jth, p.weight * wf);
+    sadd(4, weight);
+    tadd(a, a->L.esc_psd_up + ip + pm * jth, weight * wf);
     const bool rel = (gam_sk - 1) >= MCS_E_REL_PT;
     const double E_kin = rel ? (gam_sk - 1) * E0 : ptot_sk * ptot_sk / (2 * m);
-    const double eadd = E_kin * p.weight;
-    tadd(a, a.L.px_esc_feb + ion + (long long)a.P.n_ions * iter, __builtin_fabs(px) * p.weight);
-    tadd(a, a.L.energy_esc_feb + ion + (long long)a.P.n_ions * iter, eadd);
-    tadd(a, a.L.esc_energy_eff + ip + pm * ion, eadd);
-    tadd(a, a.L.esc_num_eff + ip + pm * ion, p.weight);
+    const double eadd = E_kin * weight;
+    sadd(5, __builtin_fabs(px) * weight);
+    sadd(6, eadd);
+    tadd(a, a->L.esc_energy_eff + ip + pm * ion, eadd);
+    tadd(a, a->L.esc_num_eff + ip + pm * ion, weight);
   }
 }
 
 // load a particle and run the prologue of particle_loop (src/particle_loop.jl:44-153)
-__device__ __forceinline__ void load_particle(const KArgs& a, const Lds& s, long long k, Pt& p, Rng& rng) {
-  p.weight = a.in.weight[k];
-  p.ptot_pf = a.in.ptot_pf[k];
-  p.pb_pf = a.in.pb_pf[k];
-  p.x = a.in.x_PT_cm[k];
-  p.xn_per = a.in.xn_per[k];
-  p.prp = a.in.prp_x_cm[k];
-  p.acctime = a.in.acctime_sec[k];
-  p.phi = a.in.phi_rad[k];
-  const uint32_t meta = a.in.meta[k];
+__device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h, long long k, Pt& p, Rng& rng) {
+  p.weight = a->in.weight[k];
+  p.ptot_pf = a->in.ptot_pf[k];
+  p.pb_pf = a->in.pb_pf[k];
+  p.x = a->in.x_PT_cm[k];
+  p.xn_per = a->in.xn_per[k];
+  p.prp = a->in.prp_x_cm[k];
+  p.acctime = a->in.acctime_sec[k];
+  p.phi = a->in.phi_rad[k];
+  const uint32_t meta = a->in.meta[k];
   p.i_grid = (int)(meta & 0xffffu);
   p.tcut = (int)((meta >> 16) & 0xffu);
   p.downstream = (meta >> 24) & 1u;
   p.inj = (meta >> 25) & 1u;
   p.i_grid_old = p.i_grid;
+  p.ig3 = p.i_grid;
   p.helix = 0; p.n_retro = 0;
-  const unsigned long long key = a.seed_base + (unsigned long long)(a.i_prt_offset + k + 1);
+  const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
   rng.k0 = (uint32_t)key; rng.k1 = (uint32_t)(key >> 32); rng.n = 0; rng.spare = 0.0;
 
-  p.gam_pf = mcsm::hypot1(p.ptot_pf / a.mc);
+  p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
   p.gyro_denom = s.gd[p.i_grid];
-  if (a.P.use_custom_epsB && p.x > a.P.x_grid_stop) p.gyro_denom *= __builtin_sqrt(p.x / a.P.x_grid_stop);
+  if (h.custom_epsB && p.x > h.x_grid_stop) p.gyro_denom *= __builtin_sqrt(p.x / h.x_grid_stop);
   p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
-  p.gyro_period = TWOPI_ * p.gam_pf * a.m * CC_ * p.gyro_denom;
-  p.ux = s.ux[p.i_grid]; p.uz = s.uz[p.i_grid]; p.ut = s.ut[p.i_grid];
-  p.gsf = s.gsf[p.i_grid]; p.gef = s.gef[p.i_grid];
-  p.bsin = s.bsin[p.i_grid]; p.bcos = s.bcos[p.i_grid];
+  p.gyro_period = TWOPI_ * p.gam_pf * h.m * CC_ * p.gyro_denom;
   p.i_return = -1;
   p.t_step = 0.0;
   p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
+  p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? s.tc[p.tcut - 1] : __builtin_inf();
+  p.cm_grt = -1.0; p.cm_xn = -1.0; p.cm_val = 0.0;
 }
 
 // One pass of the helix loop (src/particle_loop.jl:154-499).  Returns -1 while the
 // particle lives, else the end code: 0 = saved for the next pcut, 1..4 = i_reason.
-__device__ __forceinline__ int helix_step(const KArgs& a, const Lds& s, Rng& rng, Pt& p) {
-  const mcs_params& P = a.P;
-  const double aa = a.aa;
+__device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p) {
+  const double aa = h.aa;
   p.helix += 1;
   if (p.helix > MCS_HELIX_CAP) { cnt(a, MCS_IC_HELIX_CAP); return 1; }
 
@@ -580,62 +657,65 @@ __device__ __forceinline__ int helix_step(const KArgs& a, const Lds& s, Rng& rng
     p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   } else {
     // ---- Code Block 3
-    const double ux_o = p.ux, uz_o = p.uz, ut_o = p.ut, gsf_o = p.gsf, bsin_o = p.bsin, bcos_o = p.bcos;
-    const int ig = p.i_grid;
-    p.ux = s.ux[ig]; p.uz = s.uz[ig]; p.ut = s.ut[ig]; p.gsf = s.gsf[ig]; p.gef = s.gef[ig];
-    p.bsin = s.bsin[ig]; p.bcos = s.bcos[ig];
-    double bmag = s.bt[ig];
-    if (P.use_custom_epsB && p.x > P.x_grid_stop) {
-      bmag = s.bt[P.n_grid] * __builtin_sqrt(P.x_grid_stop / p.x);
-      p.gyro_denom = 1 / (a.zzq * bmag);
+    const int ig = p.i_grid, io = p.ig3;
+    p.ig3 = ig;
+    double bmag = 0.0;
+    if (h.custom_epsB && p.x > h.x_grid_stop) {
+      bmag = s.bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+      p.gyro_denom = 1 / (h.zzq * bmag);
     } else {
       p.gyro_denom = s.gd[ig];            // == 1/(zz*btot[ig]), tabulated per zone
     }
-    if (p.ux != ux_o) {
-      transform_p_PSP(a, p, ux_o, uz_o, ut_o, gsf_o, bcos_o, bsin_o);
+    if (ig != io && s.ux[ig] != s.ux[io]) {   // same zone => same u_x: no transform
+      const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
       p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
     }
-    if (P.energy_transfer_frac > 0 && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid) do_energy_transfer(a, p);
-
-    if (P.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
-    if (p.ptot_pf > a.pmax_cutoff) {
-      double ptot_sk, px, py, pz, gam_sk;
-      transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.ux, p.gsf, p.bcos, p.bsin, ptot_sk, px, py, pz, gam_sk);
-      if (ptot_sk > a.pmax_cutoff) return 2;
+    if (h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid) {
+      Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+      r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
     }
-    if (p.inj && p.x < P.feb_upstream) return 2;
-    if (P.age_max > 0 && p.acctime > P.age_max) return 3;
 
-    if (P.do_rad_losses && aa < 1) {
+    if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
+    if (p.ptot_pf > h.pmax_cutoff) {
+      double ptot_sk, px, py, pz, gam_sk;
+      transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, s.ux[ig], s.gsf[ig], s.bcos[ig], s.bsin[ig], ptot_sk, px, py, pz, gam_sk);
+      if (ptot_sk > h.pmax_cutoff) return 2;
+    }
+    if (p.inj && p.x < h.feb_up) return 2;
+    if (h.age_max > 0 && p.acctime > h.age_max) return 3;
+
+    if (h.rad_losses && aa < 1) {
+      if (!(h.custom_epsB && p.x > h.x_grid_stop)) bmag = s.bt[ig];
       const double ptot_old = p.ptot_pf;
-      const double B_CMB_loc = P.B_CMBz * p.gef;
+      const double B_CMB_loc = a->P.B_CMBz * s.gef[ig];
       p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, p.t_step);
       if (p.ptot_pf <= 0) {
         p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
         return 4;
       }
-      p.gam_pf = mcsm::hypot1(p.ptot_pf / a.mc);
+      p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
       p.pb_pf *= p.ptot_pf / ptot_old;
       p.p_perp *= p.ptot_pf / ptot_old;
       p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
       p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
     }
 
-    if (!P.dont_scatter) scattering(a, rng, p);
+    if (!h.dont_scatter) scattering(a, rng, p, aa, aa * MP_ * CC_, h.eta);
 
     if (p.downstream) {
-      p.acctime += p.t_step * p.gef;
-      if (P.do_tcuts) {
-        if (p.tcut > a.tb.n_tcuts) cnt(a, MCS_IC_TCUT_OVERRUN);
-        else if (p.acctime >= a.tb.tcuts[p.tcut - 1]) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
-      }
-      if (p.ptot_pf > a.pcut) return 0;   // saved for the next pcut (particle_loop.jl:361-380)
+      p.acctime += p.t_step * s.gef[ig];
+      if (h.do_tcuts) tcut_check(a, s, p, h.n_tcuts);
+      if (p.ptot_pf > h.pcut) return 0;   // saved for the next pcut (particle_loop.jl:361-380)
     }
-    p.xn_per = p.x > p.gyro_rad_tot ? P.xn_per_coarse : P.xn_per_fine;
+    p.xn_per = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
   }
 
   // ---- Code Block 2
+  const int ig3 = p.ig3;
+  const double gsf = s.gsf[ig3], bcos = s.bcos[ig3], bsin = s.bsin[ig3], ux = s.ux[ig3];
   p.x_old = p.x;
   const double phi_old = p.phi;
   p.t_step = p.gyro_period / p.xn_per;
@@ -646,11 +726,11 @@ __device__ __forceinline__ int helix_step(const KArgs& a, const Lds& s, Rng& rng
       p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
       const double x_move = p.pb_pf * p.t_step / (p.gam_pf * m);
       double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
-      if (p.bsin != 0.0) gyr = p.gyro_rad * p.bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
-      const double dx = p.gsf * (x_move * p.bcos - gyr + p.ux * p.t_step);
+      if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+      const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
       p.x = p.x_old + dx;
-      if (p.x <= 0 && p.x_old > 0 && !p.inj && (P.dont_DSA || a.inj_frac < 1)) {
-        if (P.dont_DSA || (rng.rand() > a.inj_frac)) {
+      if (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1)) {
+        if (h.dont_DSA || (rng.rand() > h.inj_frac)) {
           if (p.pb_pf < 0) p.pb_pf = -p.pb_pf; else p.phi = rng.rand() * TWOPI_;
         } else break;
       } else break;
@@ -658,37 +738,51 @@ __device__ __forceinline__ int helix_step(const KArgs& a, const Lds& s, Rng& rng
   }
   if (p.x_old < 0 && p.x >= 0) {
     p.downstream = true;
-    const double L_diff = P.eta_mfp / 3 * p.gyro_rad_tot * p.ptot_pf / (a.m * p.gam_pf * P.u2);
+    const double L_diff = h.eta / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * h.u2);
     p.prp = p.prp > L_diff ? p.prp : L_diff;
   }
   if (p.downstream && p.x < 0) p.inj = true;
 
-  if (!all_flux(a, s, p)) return 3;
+  // all_flux! (all_flux.jl:45-82): zone search; tallies only when something was crossed
+  {
+    p.i_grid_old = p.i_grid;
+    const int ne = h.n_grid + 2;
+    int found = -1;
+    if (p.x > p.x_old) {
+      for (int j = p.i_grid + 1; j < ne; ++j) if (s.x[j] > p.x) { found = j - 1; break; }
+    } else {
+      for (int j = p.i_grid; j >= 0; --j) if (s.x[j] <= p.x) { found = j; break; }
+    }
+    if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
+    p.i_grid = found;
+    if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0))
+      flux_tally(a, s, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, ig3, p.inj);
+  }
 
   // downstream_test (particle_loop.jl:595-637)
   bool do_prob_ret = true;
-  if (P.feb_downstream > 0 && p.x > P.feb_downstream) {
+  if (h.feb_down > 0 && p.x > h.feb_down) {
     p.i_return = 0; do_prob_ret = false;
   } else if (p.x > 1.1 * p.prp) {
     const double m = aa * MP_;
     double v_fac;
-    if (aa < 1 && p.ptot_pf < P.pe_crit) {
-      const double gyro_fac = P.pe_crit * CC_ * p.gyro_denom;
-      v_fac = gyro_fac * P.pe_crit / (m * P.game_crit * P.u2);
+    if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
+      const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
+      v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
     } else {
-      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * P.u2);
+      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
     }
-    const double L_diff = P.eta_mfp / 3 * v_fac;
+    const double L_diff = h.eta / 3 * v_fac;
     if (p.x > 6.91 * L_diff) { p.i_return = 0; do_prob_ret = false; }
   }
   bool lose_pt = false;
-  if (do_prob_ret) prob_return(a, s, rng, p, lose_pt);
+  if (do_prob_ret) prob_return(a, s, h, rng, p, lose_pt);
 
   if (p.i_return == 0) {
-    double vel = p.ptot_pf / a.m;
+    double vel = p.ptot_pf / h.m;
     if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
-    tadd(a, a.L.scalars + 0, p.ptot_pf / 3 * vel * p.weight * a.density);
-    tadd(a, a.L.scalars + 1, (p.gam_pf - 1) * a.m * (CC_ * CC_) * p.weight * a.density);
+    sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
+    sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
     return lose_pt ? 4 : 1;
   }
   return -1;
@@ -696,28 +790,43 @@ __device__ __forceinline__ int helix_step(const KArgs& a, const Lds& s, Rng& rng
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(256)
-mcs_k_transport(KArgs a) {
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD)
+mcs_k_transport(const KArgs* __restrict__ ka) {
+  CK* a = (CK*)ka;
   extern __shared__ double smem[];
-  const int ne = a.P.n_grid + 2, ng = a.P.n_grid;
+  const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
   Lds s;
   s.x = smem; s.ux = s.x + ne; s.uz = s.ux + ne; s.ut = s.uz + ne; s.gsf = s.ut + ne; s.gef = s.gsf + ne;
   s.bt = s.gef + ne; s.bsin = s.bt + ne; s.bcos = s.bsin + ne; s.gd = s.bcos + ne;
   s.fl = s.gd + ne;
-  s.nc = (int*)(s.fl + 3 * ng);
+  s.tc = s.fl + 3 * ng;
+  s.nc = (int*)(s.tc + ntc);
   for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    s.x[i] = a.tb.x_grid[i]; s.ux[i] = a.tb.ux[i]; s.uz[i] = a.tb.uz[i]; s.ut[i] = a.tb.utot[i];
-    s.gsf[i] = a.tb.gsf[i]; s.gef[i] = a.tb.gef[i];
-    const double bt = a.tb.btot[i], th = a.tb.theta[i];
+    s.x[i] = a->tb.x_grid[i]; s.ux[i] = a->tb.ux[i]; s.uz[i] = a->tb.uz[i]; s.ut[i] = a->tb.utot[i];
+    s.gsf[i] = a->tb.gsf[i]; s.gef[i] = a->tb.gef[i];
+    const double bt = a->tb.btot[i], th = a->tb.theta[i];
     s.bt[i] = bt;
     double sn, cs;
     mcsm::sincos(th, &sn, &cs);
     s.bsin[i] = sn; s.bcos[i] = cs;
-    s.gd[i] = 1 / (a.zzq * bt);
+    s.gd[i] = 1 / (a->zzq * bt);
   }
   for (int i = threadIdx.x; i < 3 * ng; i += blockDim.x) s.fl[i] = 0.0;
+  for (int i = threadIdx.x; i < ntc; i += blockDim.x) s.tc[i] = a->tb.tcuts[i];
   for (int i = threadIdx.x; i < ng; i += blockDim.x) s.nc[i] = 0;
+  if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
+  if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
   __syncthreads();
+
+  Hot h;
+  h.aa = a->aa; h.m = a->m; h.mc = a->mc; h.zzq = a->zzq; h.pcut = a->pcut; h.pmax_cutoff = a->pmax_cutoff;
+  h.feb_up = a->P.feb_upstream; h.feb_down = a->P.feb_downstream; h.age_max = a->P.age_max;
+  h.x_grid_stop = a->P.x_grid_stop; h.u2 = a->P.u2; h.eta = a->P.eta_mfp;
+  h.xn_fine = a->P.xn_per_fine; h.xn_coarse = a->P.xn_per_coarse; h.inj_frac = a->inj_frac;
+  h.n_grid = ng; h.i_grid_feb = a->P.i_grid_feb; h.n_tcuts = ntc; h.n_xspec = a->tb.n_xspec;
+  h.custom_epsB = a->P.use_custom_epsB != 0; h.etf = a->P.energy_transfer_frac > 0;
+  h.dont_scatter = a->P.dont_scatter != 0; h.rad_losses = a->P.do_rad_losses != 0;
+  h.do_tcuts = a->P.do_tcuts != 0; h.dont_DSA = a->P.dont_DSA != 0;
 
   Pt p;
   Rng rng;
@@ -725,6 +834,7 @@ mcs_k_transport(KArgs a) {
   long long k = -1;
   unsigned long long c_helix = 0, c_retro = 0, c_draws = 0;
   const unsigned lane = __lane_id();
+  const unsigned long long n = (unsigned long long)a->n;
 
   for (;;) {
     // ---- refill idle lanes (wave-aggregated claim)
@@ -733,16 +843,16 @@ mcs_k_transport(KArgs a) {
       const int nidle = __popcll(idle);
       const int leader = __ffsll((long long)idle) - 1;
       unsigned long long base = 0;
-      if ((int)lane == leader) base = atomicAdd(a.work_counter, (unsigned long long)nidle);
+      if ((int)lane == leader) base = atomicAdd(a->work_counter, (unsigned long long)nidle);
       base = __shfl(base, leader);
-      if (base >= (unsigned long long)a.n) {
+      if (base >= n) {
         exhausted = true;
       } else if (!active) {
         const int rank = __popcll(idle & ((1ull << lane) - 1ull));
         const unsigned long long idx = base + (unsigned long long)rank;
-        if (idx < (unsigned long long)a.n) {
+        if (idx < n) {
           k = (long long)idx;
-          load_particle(a, s, k, p, rng);
+          load_particle(a, s, h, k, p, rng);
           active = true;
         }
       }
@@ -752,24 +862,24 @@ mcs_k_transport(KArgs a) {
       continue;
     }
     if (active) {
-      const int end = helix_step(a, s, rng, p);
+      const int end = helix_step(a, s, h, rng, p);
       if (end >= 0) {
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
         if (end == 0) {
-          a.l_save[k] = 1;
-          a.sv.weight[k] = p.weight; a.sv.ptot_pf[k] = p.ptot_pf; a.sv.pb_pf[k] = p.pb_pf; a.sv.x_PT_cm[k] = p.x;
-          a.sv.xn_per[k] = p.xn_per;
-          a.sv.prp_x_cm[k] = p.x < p.prp ? p.prp : p.x * 1.1;   // quirk Q7
-          a.sv.acctime_sec[k] = p.acctime; a.sv.phi_rad[k] = p.phi;
-          a.sv.meta[k] = mcs_pack_meta(p.i_grid, p.tcut, p.downstream, p.inj);
-          gadd_u64(a.n_saved, 1ull);
+          a->l_save[k] = 1;
+          a->sv.weight[k] = p.weight; a->sv.ptot_pf[k] = p.ptot_pf; a->sv.pb_pf[k] = p.pb_pf; a->sv.x_PT_cm[k] = p.x;
+          a->sv.xn_per[k] = p.xn_per;
+          a->sv.prp_x_cm[k] = p.x < p.prp ? p.prp : p.x * 1.1;   // quirk Q7
+          a->sv.acctime_sec[k] = p.acctime; a->sv.phi_rad[k] = p.phi;
+          a->sv.meta[k] = mcs_pack_meta(p.i_grid, p.tcut, p.downstream, p.inj);
+          cnt(a, MCS_IC_COUNT);
         } else {
-          particle_finish(a, p, end);
+          particle_finish(a, s, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
         }
         cnt(a, MCS_IC_REASON0 + end);
-        if (a.f_reason) {
-          a.f_reason[k] = end; a.f_helix[k] = p.helix; a.f_retro[k] = p.n_retro; a.f_ptot[k] = p.ptot_pf; a.f_x[k] = p.x;
+        if (a->f_reason) {
+          a->f_reason[k] = end; a->f_helix[k] = p.helix; a->f_retro[k] = p.n_retro; a->f_ptot[k] = p.ptot_pf; a->f_x[k] = p.x;
         }
         active = false;
       }
@@ -782,29 +892,46 @@ mcs_k_transport(KArgs a) {
     c_retro += __shfl_down(c_retro, off);
     c_draws += __shfl_down(c_draws, off);
   }
-  if (lane == 0) {
-    if (c_helix) cnt(a, MCS_IC_STEPS_HELIX, c_helix);
-    if (c_retro) cnt(a, MCS_IC_STEPS_RETRO, c_retro);
-    if (c_draws) cnt(a, MCS_IC_RNG_DRAWS, c_draws);
+  if (lane == 0) {   // 64-bit totals go straight to the global counters (one atomic per wave)
+    if (c_helix) gadd_u64(&a->I[ng + MCS_IC_STEPS_HELIX], c_helix);
+    if (c_retro) gadd_u64(&a->I[ng + MCS_IC_STEPS_RETRO], c_retro);
+    if (c_draws) gadd_u64(&a->I[ng + MCS_IC_RNG_DRAWS], c_draws);
   }
   __syncthreads();
+  if (threadIdx.x < MCS_IC_COUNT) {
+    const unsigned int c = g_ctr[threadIdx.x];
+    if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
+  } else if (threadIdx.x == MCS_IC_COUNT) {
+    const unsigned int c = g_ctr[MCS_IC_COUNT];
+    if (c) gadd_u64(a->n_saved, (unsigned long long)c);
+  } else if (threadIdx.x < MCS_IC_COUNT + 8) {
+    const int j = threadIdx.x - MCS_IC_COUNT - 1;
+    const double v = g_sc[j];
+    const int ion = a->i_ion - 1, iter = a->i_iter - 1;
+    long long off = a->L.scalars + j;
+    if (j == 4) off = a->L.esc_flux + ion;
+    else if (j == 5) off = a->L.px_esc_feb + ion + (long long)a->P.n_ions * iter;
+    else if (j == 6) off = a->L.energy_esc_feb + ion + (long long)a->P.n_ions * iter;
+    if (v != 0.0) gadd_f64(&a->T[off], v);
+  }
   for (int i = threadIdx.x; i < ng; i += blockDim.x) {
     const double v0 = s.fl[i], v1 = s.fl[ng + i], v2 = s.fl[2 * ng + i];
-    if (v0 != 0.0) gadd_f64(&a.T[a.L.pxx_flux + i], v0);
-    if (v1 != 0.0) gadd_f64(&a.T[a.L.pxz_flux + i], v1);
-    if (v2 != 0.0) gadd_f64(&a.T[a.L.energy_flux + i], v2);
+    if (v0 != 0.0) gadd_f64(&a->T[a->L.pxx_flux + i], v0);
+    if (v1 != 0.0) gadd_f64(&a->T[a->L.pxz_flux + i], v1);
+    if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
     const int c = s.nc[i];
-    if (c) gadd_u64(&a.I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
+    if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
   }
 }
 
-extern "C" size_t mcs_transport_smem_bytes(int n_grid) {
+extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) {
   const int ne = n_grid + 2;
-  return (size_t)(10 * ne + 3 * n_grid) * sizeof(double) + (size_t)n_grid * sizeof(int);
+  return (size_t)(10 * ne + 3 * n_grid + n_tcuts) * sizeof(double) + (size_t)n_grid * sizeof(int);
 }
 
-extern "C" hipError_t mcs_launch_transport(const KArgs* a, int blocks, int threads, hipStream_t st) {
-  const size_t sm = mcs_transport_smem_bytes(a->P.n_grid);
-  hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), sm, st, *a);
+// `a_dev`: device copy of the launch constants (written by the caller on `st`).
+extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st) {
+  const size_t sm = mcs_transport_smem_bytes(n_grid, n_tcuts);
+  hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), sm, st, a_dev);
   return hipGetLastError();
 }
