@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the transport path (BASELINE.json):
+particle-scatter steps/s and wall time per iteration, 10^6 protons per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration (`i_iter` body of src/main_loops.jl:52-391) of the
+workload: BASELINE config[1] -- 10^6 protons per GPU, single unmodified gamma0 = 5
+shock, fp64, the 45 stock pcuts, scattering and DSA on -- i.e. init_pop (K3), then
+for every pcut the transport kernel (K1) + compaction/splitting (K2), then the
+merge of the tallies.  Weak scaling: every rank carries 10^6 particles of ONE global
+population of N x 10^6 (global RNG keys), per-pcut all-gather of n_saved, one
+sum-all-reduce of the tallies per iteration (RCCL).  Synthetic data: the thermal
+injection of the reference's own initialiser.  `value` = total (helix + retro) steps
+of all ranks / max-over-ranks wall time of the K timed steps.
+
+Extra objects in the JSON line:
+  roofline     the transport kernel against the fp64 VALU peak (78.6 TFLOP/s): the path
+               is scalar fp64 arithmetic, neither HBM- nor MFMA-bound;
+               achieved = 400 algorithmic flop/step x steps / kernel time (HIP events on
+               the kernel's stream, summed over the launches of the timed region).
+  cpu_baseline the CPU oracle (C++ restatement, glibc libm, OpenMP over particles on all
+               host cores) on a bounded sample of the same workload -- a surrogate for
+               the Julia reference, which cannot run here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP = 400.0          # weighted algorithmic fp64 flop per step
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
+
+
+def cpu_baseline(mcs, n_sample, n_itrs=1):
+    """Timed CPU leg (rank 0, N=1 only): the oracle is used here as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))           # the GPU box gives one GPU a share of the host cores
+    cfg = mcs.inputs.Config(N_PTS_INJ=n_sample, N_PTS_PCUT=n_sample, N_PTS_PCUT_HI=n_sample)
+    prob = mcs.inputs.build_problem(cfg)
+    be = orc.OracleBackend(mcs.capi, "libm", nthreads=cores)
+    be.create(prob)
+    t0 = time.perf_counter()
+    res = mcs.driver.run(prob, be, None, n_itrs=n_itrs)
+    dt = time.perf_counter() - t0
+    steps = res.steps_helix + res.steps_retro
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": steps / dt, "unit": "particle-scatter steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample} protons, all 45 pcuts, {n_itrs} iteration, {steps} steps in {dt:.1f} s; "
+                      f"C++ surrogate of the Julia reference (glibc libm, OpenMP dynamic over particles); cpu: {model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import _mcs_loader
+    mcs = _mcs_loader.load()
+    from mcs_amd import hip_backend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_global = args.particles * world
+    n_itrs = args.steps + args.warmup
+    cfg = mcs.inputs.Config(N_PTS_INJ=n_global, N_PTS_PCUT=n_global, N_PTS_PCUT_HI=n_global, num_iterations=n_itrs)
+    prob = mcs.inputs.build_problem(cfg)
+    be = hip_backend.HipBackend(local)
+    be.create(prob)
+    comm = mcs.driver.Comm(world > 1, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = {"steps": 0, "kernel_ms": 0.0, "t": None}
+    marks = {}
+
+    def on_species_end(i_iter, i_ion, G_f, G_i):
+        # called at the end of each iteration's (single) species: iteration boundary
+        ng = prob.n_grid
+        IC = mcs.capi.IC
+        marks[i_iter] = (time.perf_counter(), int(G_i[ng + IC["STEPS_HELIX"]] + G_i[ng + IC["STEPS_RETRO"]]))
+        if i_iter == args.warmup:
+            barrier()
+            marks["t0"] = time.perf_counter()
+
+    if args.warmup == 0:
+        barrier()
+        marks["t0"] = time.perf_counter()
+    res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, on_species_end=on_species_end)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - marks["t0"]
+    steps_total = marks[n_itrs][1] - (marks[args.warmup][1] if args.warmup > 0 else 0)
+    kern_ms = sum(s.kernel_ms for s in res.stats if s.i_iter > args.warmup)
+    n_launch = sum(1 for s in res.stats if s.i_iter > args.warmup)
+    # local steps of this rank in the timed region (for the per-kernel roofline)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        value = steps_total / elapsed
+        local_steps = steps_total / world          # shards are balanced by construction
+        ach = local_steps * FLOP_PER_STEP / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "particle-scatter steps/sec + wall-time per iter, 10^6 particles, 1->8 MI355X",
+            "value": value, "unit": "particle-scatter steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config[1]: 1e6 protons per GPU, single unmodified gamma0=5 shock, "
+                                   "45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration",
+                       "particles_per_gpu": args.particles, "particles_total": n_global,
+                       "steps_per_iteration": steps_total / args.steps,
+                       "parallelism": f"particle shards x{world}, all-gather(n_saved)/pcut, all-reduce(tallies)/iter"},
+            "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "mcs_k_transport", "launches": n_launch,
+                         "avg_launch_ms": kern_ms / max(n_launch, 1),
+                         "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
+                         "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "
+                                 "HBM traffic is << 1 B/step (68 B in + 69 B out per particle per pcut)"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -478,7 +478,10 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
   return r;
 }
 
-// hot-loop constants, fetched once per wave (SGPRs)
+__device__ __forceinline__ double vconst(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int vconsti(int x) { asm volatile("" : "+v"(x)); return x; }
+
+// hot-loop constants, fetched once per wave
 struct Hot {
   double aa, m, mc, zzq, pcut, pmax_cutoff, feb_up, feb_down, age_max, x_grid_stop, u2, eta, xn_fine, xn_coarse, inj_frac;
   int n_grid, i_grid_feb, n_tcuts, n_xspec;
@@ -818,15 +821,25 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
   __syncthreads();
 
+  // Hot-loop constants are parked in VGPRs behind an opaque move: the compiler can then
+  // neither re-load them from the constant buffer inside the loop (s_load + s_waitcnt
+  // lgkmcnt(0): ~20 scalar loads per step were 85 % of a lone wave's cycles) nor spill them
+  // as SGPRs.  ~40 VGPRs, bought back by never waiting on memory in the loop.
   Hot h;
-  h.aa = a->aa; h.m = a->m; h.mc = a->mc; h.zzq = a->zzq; h.pcut = a->pcut; h.pmax_cutoff = a->pmax_cutoff;
-  h.feb_up = a->P.feb_upstream; h.feb_down = a->P.feb_downstream; h.age_max = a->P.age_max;
-  h.x_grid_stop = a->P.x_grid_stop; h.u2 = a->P.u2; h.eta = a->P.eta_mfp;
-  h.xn_fine = a->P.xn_per_fine; h.xn_coarse = a->P.xn_per_coarse; h.inj_frac = a->inj_frac;
-  h.n_grid = ng; h.i_grid_feb = a->P.i_grid_feb; h.n_tcuts = ntc; h.n_xspec = a->tb.n_xspec;
-  h.custom_epsB = a->P.use_custom_epsB != 0; h.etf = a->P.energy_transfer_frac > 0;
-  h.dont_scatter = a->P.dont_scatter != 0; h.rad_losses = a->P.do_rad_losses != 0;
-  h.do_tcuts = a->P.do_tcuts != 0; h.dont_DSA = a->P.dont_DSA != 0;
+  h.aa = vconst(a->aa); h.m = vconst(a->m); h.mc = vconst(a->mc); h.zzq = vconst(a->zzq); h.pcut = vconst(a->pcut);
+  h.pmax_cutoff = vconst(a->pmax_cutoff);
+  h.feb_up = vconst(a->P.feb_upstream); h.feb_down = vconst(a->P.feb_downstream); h.age_max = vconst(a->P.age_max);
+  h.x_grid_stop = vconst(a->P.x_grid_stop); h.u2 = vconst(a->P.u2); h.eta = vconst(a->P.eta_mfp);
+  h.xn_fine = vconst(a->P.xn_per_fine); h.xn_coarse = vconst(a->P.xn_per_coarse); h.inj_frac = vconst(a->inj_frac);
+  h.n_grid = vconsti(ng); h.i_grid_feb = vconsti(a->P.i_grid_feb); h.n_tcuts = vconsti(ntc); h.n_xspec = vconsti(a->tb.n_xspec);
+  {
+    const int flags = (a->P.use_custom_epsB != 0 ? 1 : 0) | (a->P.energy_transfer_frac > 0 ? 2 : 0) |
+                      (a->P.dont_scatter != 0 ? 4 : 0) | (a->P.do_rad_losses != 0 ? 8 : 0) |
+                      (a->P.do_tcuts != 0 ? 16 : 0) | (a->P.dont_DSA != 0 ? 32 : 0);
+    const int fv = vconsti(flags);
+    h.custom_epsB = fv & 1; h.etf = fv & 2; h.dont_scatter = fv & 4; h.rad_losses = fv & 8; h.do_tcuts = fv & 16;
+    h.dont_DSA = fv & 32;
+  }
 
   Pt p;
   Rng rng;

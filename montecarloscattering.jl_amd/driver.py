@@ -158,6 +158,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             # species end: merge the partial tallies of all ranks (C1)
             f, i = backend.read_tallies()
             if comm.world > 1:
+                if not is_root:   # every rank carried a full copy of the received-energy pool
+                    L.view(f, "energy_recv_pool")[...] = 0.0
                 tf, ti = torch.from_numpy(f), torch.from_numpy(i)
                 if comm.device is not None and comm.device.type == "cuda":
                     tf_d, ti_d = tf.to(comm.device), ti.to(comm.device)

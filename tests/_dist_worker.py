@@ -1,0 +1,47 @@
+"""Worker for the multi-process driver tests: one rank of a torch.distributed job running
+the host driver with the CPU oracle injected as backend (tests only) or the HIP backend."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out, backend_kind, N, npc = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    import torch
+    import torch.distributed as dist
+    import _mcs_loader
+    mcs = _mcs_loader.load()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo" if backend_kind == "oracle" else "nccl", rank=rank, world_size=world)
+    two_species = len(sys.argv) > 5 and sys.argv[5] == "2"
+    kw = {}
+    if two_species:
+        kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)], energy_transfer_frac=0.1)
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2, **kw)
+    prob = mcs.inputs.build_problem(cfg)
+    if backend_kind == "oracle":
+        import orc
+        be = orc.OracleBackend(mcs.capi, "det", 1)
+        dev = None
+    else:
+        from mcs_amd import hip_backend
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        be = hip_backend.HipBackend(local)
+        dev = torch.device("cuda", local)
+    be.create(prob)
+    comm = mcs.driver.Comm(True, dev)
+    res = mcs.driver.run(prob, be, comm, n_itrs=2, max_pcuts=npc)
+    if rank == 0:
+        np.savez(out, f=res.tallies_f64, i=res.tallies_i64,
+                 stats=np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in res.stats]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
