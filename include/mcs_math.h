@@ -39,8 +39,16 @@
  * ~150 VGPRs of polynomial coefficients live across the whole transport loop.  The value
  * is unchanged, so results are bit-identical with and without it. */
 #if defined(__HIP_DEVICE_COMPILE__)
-namespace mcsm { __device__ __forceinline__ double sc_(double c) { asm volatile("" : "+s"(c)); return c; } }
-#define MCS_SC(c) (::mcsm::sc_(c))
+namespace mcsm {
+/* two s_mov_b32 with literal operands write the constant into a fresh SGPR pair */
+template <unsigned LO, unsigned HI> __device__ __forceinline__ double sc2_() {
+  unsigned lo, hi;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+}
+#define MCS_SC(c) (::mcsm::sc2_<(unsigned)(__builtin_bit_cast(unsigned long long, (double)(c)) & 0xffffffffull), \
+                                (unsigned)(__builtin_bit_cast(unsigned long long, (double)(c)) >> 32)>())
 #else
 #define MCS_SC(c) (c)
 #endif
@@ -54,7 +62,28 @@ namespace mcsm { __device__ __forceinline__ double sc_(double c) { asm volatile(
 namespace mcsm {
 
 MCS_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* sqrt_: correctly rounded fp64 square root.  On gfx950 hipcc expands __builtin_sqrt to
+ * v_rsq_f64 + two Goldschmidt/Newton steps wrapped in an exponent rescale (for arguments
+ * below 2^-767) and a class test: 17 instructions.  With MCS_DEVICE_FAST_SQRT the same
+ * iteration is used WITHOUT the rescale (the path never takes roots of subnormal-range
+ * numbers): 10 instructions, identical bits for every normal argument and for +0. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MCS_DEVICE_FAST_SQRT)
+MCS_HD double sqrt_(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+#else
 MCS_HD double sqrt_(double a) { return __builtin_sqrt(a); }
+#endif
 MCS_HD double abs_(double a) { return __builtin_fabs(a); }
 MCS_HD double copysign_(double a, double b) { return __builtin_copysign(a, b); }
 
@@ -132,6 +161,43 @@ MCS_HD double asin(double x) {
   double s = small ? ax : sqrt_(z);
   double t = fma_(s * z, asin_core(z), s);            /* asin(s) */
   double big = MCS_SC(MCS_PIO2_DD_0) - (2.0 * t - MCS_PIO2_DD_1);
+  return copysign_(small ? t : big, x);
+}
+
+/* ---- the same sincos / asin with the polynomial coefficients taken from a caller-held
+ * table instead of literals.  The HIP transport kernel keeps the 25 hot coefficients in
+ * VGPRs for the whole loop (no per-use constant materialisation); arithmetic, order and
+ * results are identical to sincos()/asin() above. */
+struct HotCoef {
+  double S0, S1, S2, S3, S4, S5;          /* MCS_SIN_0..5 */
+  double C0, C1, C2, C3, C4, C5;          /* MCS_COS_0..5 */
+  double A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11, A12;   /* MCS_ASIN_0..12 */
+};
+MCS_HD void sincos_t(double x, double* s, double* c, const HotCoef& k) {
+  int n; double r = reduce_pio2(x, &n);
+  const double z = r * r;
+  double ps = k.S5;
+  ps = fma_(ps, z, k.S4); ps = fma_(ps, z, k.S3); ps = fma_(ps, z, k.S2); ps = fma_(ps, z, k.S1); ps = fma_(ps, z, k.S0);
+  double pc = k.C5;
+  pc = fma_(pc, z, k.C4); pc = fma_(pc, z, k.C3); pc = fma_(pc, z, k.C2); pc = fma_(pc, z, k.C1); pc = fma_(pc, z, k.C0);
+  const double sr = fma_(r * z, ps, r);
+  const double cr = fma_(z * z, pc, fma_(-0.5, z, 1.0));
+  double a = (n & 1) ? cr : sr;
+  double b = (n & 1) ? sr : cr;
+  *s = (n & 2) ? -a : a;
+  *c = ((n + 1) & 2) ? -b : b;
+}
+MCS_HD double asin_t(double x, const HotCoef& k) {
+  double ax = abs_(x);
+  bool small = ax < 0.5;
+  double z = small ? x * x : (1.0 - ax) * 0.5;
+  double s = small ? ax : sqrt_(z);
+  double p = k.A12;
+  p = fma_(p, z, k.A11); p = fma_(p, z, k.A10); p = fma_(p, z, k.A9); p = fma_(p, z, k.A8); p = fma_(p, z, k.A7);
+  p = fma_(p, z, k.A6); p = fma_(p, z, k.A5); p = fma_(p, z, k.A4); p = fma_(p, z, k.A3); p = fma_(p, z, k.A2);
+  p = fma_(p, z, k.A1); p = fma_(p, z, k.A0);
+  double t = fma_(s * z, p, s);
+  double big = MCS_SC(MCS_PIO2_DD_0) - (2.0 * t - MCS_SC(MCS_PIO2_DD_1));
   return copysign_(small ? t : big, x);
 }
 

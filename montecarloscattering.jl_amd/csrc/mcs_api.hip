@@ -15,6 +15,7 @@
 
 extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
+int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
                                unsigned int* block_counts, unsigned long long* block_offsets,
@@ -198,7 +199,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   if (p->use_custom_frg) return fail("Use of custom f(r_g) not yet supported. Add functionality or use standard. (src/scattering.jl:52-53)");
   if (!p->do_retro) return fail("Code not set up for analytical PRP calculations. (src/prob_return.jl:134)");
   if (p->num_psd_mom_bins + 1 > MCS_PSD_MAX || p->num_psd_tht_bins + 1 > MCS_PSD_MAX) return fail("mcs_create: psd bins exceed psd_max (src/parameters.jl:18)");
-  if (p->n_grid < 1 || p->n_grid + 2 > 65535) return fail("mcs_create: n_grid out of range");
+  if (p->n_grid < 1 || p->n_grid + 2 > mcs_transport_max_entries()) return fail("mcs_create: n_grid + 2 exceeds the LDS table size (208 entries; psd_max = 200 in src/parameters.jl:18)");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail("mcs_create: no HIP device visible; the transport path has no CPU fallback");

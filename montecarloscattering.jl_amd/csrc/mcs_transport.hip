@@ -32,6 +32,7 @@
 // Values that are pure functions of unchanged inputs (per-zone sin/cos/1/(qB),
 // cos_max of the scattering cone) are cached, which does not change a bit.
 #include "mcs_device.h"
+#define MCS_DEVICE_FAST_SQRT 1
 #include "../../include/mcs_math.h"
 
 #pragma clang fp contract(off)
@@ -63,13 +64,38 @@ namespace {
 #define MP_ MCS_SC(MCS_MP)
 #define CC_ MCS_SC(MCS_C)
 
+// ---- correctly rounded fp64 division without the range rescale ---------------------------
+// hipcc expands a/b to div_scale x2, rcp, two Newton steps, one quotient correction, div_fmas
+// and div_fixup (11 VALU); the scaling only matters for operands near the ends of the exponent
+// range, which the path never divides.  rcp_refined(b) is the twice-refined reciprocal of that
+// very sequence, div_r(a,b,r) its quotient step: bit-identical quotients in 8 instructions,
+// and the reciprocal can be shared by divisions with the same denominator (pb/ptot and
+// p_perp/ptot, scattering.jl:65-66) or cached while the denominator is unchanged.
+__device__ __forceinline__ double rcp_refined(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_r(double a, double b, double r) {
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
+}
+__device__ __forceinline__ double fdiv(double a, double b) { return div_r(a, b, rcp_refined(b)); }
+#define FSQRT(x) (mcsm::sqrt_(x))
+
 // ---- Philox4x32-10 ------------------------------------------------------------
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                              uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;   // one v_mad_u64_u32 each
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -96,14 +122,32 @@ struct Rng {
     spare = u64_to_unit(o2, o3);
     return u64_to_unit(o0, o1);
   }
+  // Two consecutive draws (the pair of src/scattering.jl:68,71) with ONE Philox block and no
+  // branch on the parity of the draw counter: the block holding draw n+1 is always needed.
+  __device__ __forceinline__ void pair(double& u1, double& u2) {
+    const uint32_t j = n;
+    n = j + 2u;
+    uint32_t o0, o1, o2, o3;
+    philox_block((j + 1u) >> 1, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
+    const double a = u64_to_unit(o0, o1), b = u64_to_unit(o2, o3);
+    const bool odd = (j & 1u) != 0u;
+    u1 = odd ? spare : a;
+    u2 = odd ? a : b;
+    spare = b;
+  }
 };
 
-// ---- LDS view -------------------------------------------------------------------
-struct Lds {
-  double *x, *ux, *uz, *ut, *gsf, *gef, *bt, *bsin, *bcos, *gd;   // n_grid+2 each
-  double *fl;                                                   // 3*n_grid flux staging
-  double *tc;                                                   // n_tcuts time cuts
-  int* nc;                                                      // n_grid crossings staging
+// ---- LDS (static layout: compile-time addresses, no pointer registers) -----------------
+// 10 tables of n_grid+2 entries (<= MCS_MAXNE, checked by mcs_create), flux / crossing /
+// counter / scalar staging, time cuts: 23 KB per workgroup.
+#define MCS_MAXNE 208
+__shared__ double S_x[MCS_MAXNE], S_ux[MCS_MAXNE], S_uz[MCS_MAXNE], S_ut[MCS_MAXNE], S_gsf[MCS_MAXNE], S_gef[MCS_MAXNE],
+    S_bt[MCS_MAXNE], S_bsin[MCS_MAXNE], S_bcos[MCS_MAXNE], S_gd[MCS_MAXNE];
+__shared__ double S_fl[3 * MCS_MAXNE];      // pxx | pxz | energy flux staging, stride MCS_MAXNE
+__shared__ double S_tc[MCS_NA_C];           // time cuts
+__shared__ int S_nc[MCS_MAXNE];             // num_crossings staging
+struct Lds {                                // kept as an (empty) handle so call sites read the same
+  static constexpr double* x = nullptr;
 };
 
 // ---- particle state (registers) ---------------------------------------------------
@@ -112,7 +156,11 @@ struct Lds {
 // particle was in when Code Block 3 last ran; they are re-read from LDS where needed.
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
+  double dphi;                   // 2pi / xn_per, recomputed only when xn_per changes (particle_loop.jl:529)
   double gyro_denom, gyro_rad, gyro_rad_tot, gyro_period, t_step;
+  double gp_key;                 // gyro_period that t_step was computed from (t_step = gyro_period / xn_per)
+  double rp_key, rp_val;         // refined 1/ptot_pf for the ptot_pf it was computed from
+  double rg_key, rg_val;         // refined 1/(gam_pf*m) for the gam_pf it was computed from
   double tcut_next;              // tcuts[tcut-1] (LDS) or +inf
   double cm_grt, cm_xn, cm_val;  // cache of cos_max for (gyro_rad_tot, xn_per) (scattering.jl:60)
   int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
@@ -197,8 +245,8 @@ struct Mom { double ptot, pb, pperp, gam, phi; };
 __device__ MCS_COLD Mom transform_p_PSP(CK* a, Lds s, int io, int in, double r_pb, double r_pperp, double r_gam,
                                             double r_phi) {
   const double aa = a->aa;
-  const double ux_o = s.ux[io], uz_o = s.uz[io], ut_o = s.ut[io], gsf_o = s.gsf[io], bcos_o = s.bcos[io], bsin_o = s.bsin[io];
-  const double ux = s.ux[in], uz = s.uz[in], ut = s.ut[in], gsf = s.gsf[in], bcos = s.bcos[in], bsin = s.bsin[in];
+  const double ux_o = S_ux[io], uz_o = S_uz[io], ut_o = S_ut[io], gsf_o = S_gsf[io], bcos_o = S_bcos[io], bsin_o = S_bsin[io];
+  const double ux = S_ux[in], uz = S_uz[in], ut = S_ut[in], gsf = S_gsf[in], bcos = S_bcos[in], bsin = S_bsin[in];
   double phi_p = r_phi + HALFPI_;
   const double m = aa * MP_;
   const double mc = m * CC_;
@@ -242,7 +290,7 @@ __device__ MCS_COLD Mom transform_p_PSP(CK* a, Lds s, int io, int in, double r_p
 }
 
 // src/scattering.jl:29-101
-__device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, double mc, double eta) {
+__device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, double mc, double eta, const mcsm::HotCoef& kc) {
   double grt;
   if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
     grt = a->P.pe_crit * CC_ * p.gyro_denom;
@@ -260,26 +308,29 @@ __device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, do
   }
   const double cos_max = p.cm_val;
 
-  const double cos_old = p.pb_pf / p.ptot_pf;
-  const double sin_old = p.p_perp / p.ptot_pf;
-  const double cos_d = 1 - rng.rand() * (1 - cos_max);
-  const double sin_d = __builtin_sqrt(1 - cos_d * cos_d);
-  const double phi_scat = rng.rand() * TWOPI_ - PI_;
+  if (p.ptot_pf != p.rp_key) { p.rp_val = rcp_refined(p.ptot_pf); p.rp_key = p.ptot_pf; }
+  const double cos_old = div_r(p.pb_pf, p.ptot_pf, p.rp_val);      // == pb_pf / ptot_pf
+  const double sin_old = div_r(p.p_perp, p.ptot_pf, p.rp_val);     // == p_perp / ptot_pf
+  double U1, U2;
+  rng.pair(U1, U2);
+  const double cos_d = 1 - U1 * (1 - cos_max);
+  const double sin_d = FSQRT(1 - cos_d * cos_d);
+  const double phi_scat = U2 * TWOPI_ - PI_;
   double s_ps, c_ps;
-  mcsm::sincos(phi_scat, &s_ps, &c_ps);
+  mcsm::sincos_t(phi_scat, &s_ps, &c_ps, kc);
   const double cos_new = cos_old * cos_d + sin_old * sin_d * c_ps;
   double arg = 1 - cos_new * cos_new;
   if (arg < 0) arg = 0;
-  const double sin_new = __builtin_sqrt(arg);
+  const double sin_new = FSQRT(arg);
   p.pb_pf = p.ptot_pf * cos_new;
   p.p_perp = p.ptot_pf * sin_new;
   const double phi_p_old = p.phi + HALFPI_;
-  double phi_p_new = phi_p_old;
-  if (sin_new != 0) {
-    double sd = s_ps * sin_d / sin_new;
-    if (__builtin_fabs(sd) > SIN_UL) sd = __builtin_copysign(SIN_UL, sd);
-    phi_p_new += mcsm::asin(sd);
-  }
+  // get_sine_adjustment (scattering.jl:93-101), evaluated unconditionally and selected: for
+  // sin_new == 0 the quotient is inf/NaN and is discarded.
+  double sd = fdiv(s_ps * sin_d, sin_new);
+  sd = __builtin_fabs(sd) > SIN_UL ? __builtin_copysign(SIN_UL, sd) : sd;
+  const double adj = mcsm::asin_t(sd, kc);
+  const double phi_p_new = sin_new != 0 ? phi_p_old + adj : phi_p_old;
   p.phi = phi_p_new - HALFPI_;
 }
 
@@ -303,15 +354,6 @@ __device__ MCS_COLD void tcut_track(CK* a, int tcut_curr, double weight, double 
   const int i_pt = bin_momentum(a, ptot_pf);
   tadd(a, a->L.spectra_coupled + i_pt + (long long)(MCS_PSD_MAX + 1) * ((tcut_curr - 1) + (long long)MCS_NA_C * ion), weight);
 }
-__device__ __forceinline__ void tcut_check(CK* a, const Lds& s, Pt& p, int n_tcuts) {
-  if (p.tcut > n_tcuts) { cnt(a, MCS_IC_TCUT_OVERRUN); return; }   // D4
-  if (p.acctime >= p.tcut_next) {
-    tcut_track(a, p.tcut, p.weight, p.ptot_pf);
-    p.tcut += 1;
-    p.tcut_next = p.tcut <= n_tcuts ? s.tc[p.tcut - 1] : __builtin_inf();
-  }
-}
-
 // Tally part of all_flux! (src/all_flux.jl:84-161: transform, calculate_x_spec_spectra!,
 // F_stream!, FEB tracker), entered only when the zone changed (or i_grid <= i_grid_feb,
 // or x_spec detectors exist).  By-value arguments: nothing of the caller is forced to memory.
@@ -320,7 +362,7 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
                                         int ig3, bool inj) {
   const auto& P = a->P;
   const double aa = a->aa;
-  const double ux = s.ux[ig3], gsf = s.gsf[ig3], bcos = s.bcos[ig3], bsin = s.bsin[ig3];
+  const double ux = S_ux[ig3], gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3];
   double ptot_sk, px, py, pz, gam_sk;
   transform_p_PS(aa, pb_pf, p_perp, gam_pf, phi, ux, gsf, bcos, bsin, ptot_sk, px, py, pz, gam_sk);
   const double m = aa * MP_;
@@ -370,17 +412,17 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
   bool have_sf = false;
   for (int i = i_first; down ? i <= i_last : i >= i_last; i += step) {
     if (inj_check && inj && i <= P.i_grid_feb) continue;
-    ladd_f64(&s.fl[i - 1], f_pxx);
-    ladd_f64(&s.fl[ng + i - 1], f_pxz);
-    ladd_f64(&s.fl[2 * ng + i - 1], f_en);
+    ladd_f64(&S_fl[i - 1], f_pxx);
+    ladd_f64(&S_fl[MCS_MAXNE + i - 1], f_pxz);
+    ladd_f64(&S_fl[2 * MCS_MAXNE + i - 1], f_en);
     if (inj) {
       tadd(a, a->L.psd + i_pt + a->L.psd_stride_tht * jth + a->L.psd_stride_zone * (long long)(i - 1), tw);
     } else {
       if (P.track_thermal) {   // A9: bin the thermal crossing instead of appending to a list
         if (!have_sf) { k_sf = bin_momentum(a, ptot_sk); j_sf = bin_angle(a, px, ptot_sk); have_sf = true; }
         tadd(a, a->L.therm_sf + k_sf + a->L.psd_stride_tht * j_sf + a->L.psd_stride_zone * (long long)(i - 1), tw);
-        const double gam = s.gsf[i];
-        const double beta = s.ux[i] / CC_;
+        const double gam = S_gsf[i];
+        const double beta = S_ux[i] / CC_;
         const double E0 = a->m * CC_ * CC_;
         const double pc = ptot_sk * CC_;
         const double etot = __builtin_sqrt(pc * pc + E0 * E0);
@@ -391,7 +433,7 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
         const int j_pf = bin_angle(a, px_Xf, pt_Xf);
         tadd(a, a->L.therm_pf + k_pf + a->L.psd_stride_tht * j_pf + a->L.psd_stride_zone * (long long)(i - 1), tw);
       }
-      ladd_i32(&s.nc[i - 1], 1);
+      ladd_i32(&S_nc[i - 1], 1);
     }
   }
   if (inj && x < P.feb_upstream && x_old >= P.feb_upstream) {
@@ -417,12 +459,12 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
   const double xn_per = MCS_RETRO_XN_PER;
   const double phi_step = TWOPI_ / xn_per;
   const double t_step_fac = TWOPI_ * aa * MP_ * CC_ * r.gyro_denom / xn_per;
-  const double ux_sk = -s.ux[ng];
-  const double gsf = s.gsf[ng];
-  const double gef = s.gef[ng];
-  double B = s.bt[ng];
+  const double ux_sk = -S_ux[ng];
+  const double gsf = S_gsf[ng];
+  const double gef = S_gef[ng];
+  double B = S_bt[ng];
   if (P.use_custom_epsB) B *= __builtin_sqrt(P.x_grid_stop / prp);
-  const double bcos = s.bcos[ng], bsin = s.bsin[ng];
+  const double bcos = S_bcos[ng], bsin = S_bsin[ng];
   const double B_CMB_loc = P.B_CMBz * gef;
   double B2_tot = B * B + B_CMB_loc * B_CMB_loc;
   r.lose_pt = false;
@@ -435,7 +477,7 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
     const double x_PT_old = x_PT;
     const double phi_old = r.phi;
     if (P.use_custom_epsB) {
-      B = s.bt[ng] * __builtin_sqrt(P.x_grid_stop / x_PT);
+      B = S_bt[ng] * __builtin_sqrt(P.x_grid_stop / x_PT);
       B2_tot = B * B + B_CMB_loc * B_CMB_loc;
       r.gyro_denom = 1 / (a->zzq * B);
     }
@@ -452,7 +494,7 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
       else if (r.acctime >= r.tcut_next) {
         tcut_track(a, r.tcut, weight, r.ptot);
         r.tcut += 1;
-        r.tcut_next = r.tcut <= n_tcuts ? s.tc[r.tcut - 1] : __builtin_inf();
+        r.tcut_next = r.tcut <= n_tcuts ? S_tc[r.tcut - 1] : __builtin_inf();
       }
     }
     r.phi = TWOPI_ * rng.rand();
@@ -481,60 +523,12 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
 __device__ __forceinline__ double vconst(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int vconsti(int x) { asm volatile("" : "+v"(x)); return x; }
 
-// hot-loop constants, fetched once per wave
+// hot-loop constants, fetched once per wave and parked in VGPRs (see the kernel prologue)
 struct Hot {
   double aa, m, mc, zzq, pcut, pmax_cutoff, feb_up, feb_down, age_max, x_grid_stop, u2, eta, xn_fine, xn_coarse, inj_frac;
   int n_grid, i_grid_feb, n_tcuts, n_xspec;
   bool custom_epsB, etf, dont_scatter, rad_losses, do_tcuts, dont_DSA;
 };
-
-// src/prob_return.jl:36-173
-__device__ __forceinline__ void prob_return(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, bool& lose_pt) {
-  const auto& P = a->P;
-  const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
-  p.i_return = 2;
-  lose_pt = false;
-  if (p.x < x_grid_stop) {
-  } else if (p.x_old < x_grid_stop && x_grid_stop <= p.x) {
-    double gyro_tmp;
-    if (h.custom_epsB && p.x > x_grid_stop) gyro_tmp = __builtin_sqrt(x_grid_stop / p.x); else gyro_tmp = 1.0;
-    const double grt = p.ptot_pf * CC_ * gyro_tmp / (MCS_QCGS * P.bmag2);
-    const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
-    p.prp = p.x + 3 * L_diff;
-  } else if (p.x_old < p.prp && p.x >= p.prp) {
-    const double vt = p.ptot_pf / (p.gam_pf * aa * MP_);
-    const double q = (vt - u2) / (vt + u2);
-    const double prob_ret = q * q;
-    if (vt < u2 || rng.rand() > prob_ret) {
-      p.i_return = 0;
-    } else {
-      p.i_return = 1;
-      Retro r;
-      r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
-      r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = p.tcut_next; r.tcut = p.tcut;
-      r.n_retro = p.n_retro; r.rng_n = rng.n; r.rng_spare = rng.spare; r.lose_pt = false;
-      r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
-      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
-      p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut_next = r.tcut_next; p.tcut = r.tcut;
-      p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
-      if (lose_pt) p.i_return = 0;
-      p.x = p.prp;
-    }
-  } else {
-    if (aa < 1 && p.ptot_pf < a->pcut_prev && p.helix % 1000 == 0) {
-      const double grt = p.ptot_pf * CC_ * p.gyro_denom;
-      const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
-      if (p.x > 2.0e3 * L_diff) {
-        p.prp = 0.8 * p.x;
-      } else {
-        const double r = a->pcut_prev / p.ptot_pf;
-        const double r2 = r * r;
-        const double alt = x_grid_stop + L_diff * (r2 * r2 * r);
-        p.prp = p.prp < alt ? p.prp : alt;
-      }
-    }
-  }
-}
 
 // src/particle_loop.jl:652-723
 __device__ MCS_COLD Mom do_energy_transfer(CK* a, int i_grid, int i_grid_old, double weight, Mom r) {
@@ -590,7 +584,7 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
   const double m = aa * MP_;
   const double E0 = m * (CC_ * CC_);
   double ptot_sk, px, py, pz, gam_sk;
-  transform_p_PS(aa, pb_pf, p_perp, gam_pf, phi, s.ux[ig3], s.gsf[ig3], s.bcos[ig3], s.bsin[ig3], ptot_sk, px, py, pz, gam_sk);
+  transform_p_PS(aa, pb_pf, p_perp, gam_pf, phi, S_ux[ig3], S_gsf[ig3], S_bcos[ig3], S_bsin[ig3], ptot_sk, px, py, pz, gam_sk);
   const int ip = bin_momentum(a, ptot_sk);
   const int jth = bin_angle(a, px, ptot_sk);
   double wf;
@@ -610,6 +604,53 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
     sadd(6, eadd);
     tadd(a, a->L.esc_energy_eff + ip + pm * ion, eadd);
     tadd(a, a->L.esc_num_eff + ip + pm * ion, weight);
+  }
+}
+
+// src/prob_return.jl:36-173, entered only when it has something to do (the caller has
+// already set i_return = 2 and filtered the no-op cases).
+__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, bool& lose_pt) {
+  const auto& P = a->P;
+  const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
+  if (p.x < x_grid_stop) {
+  } else if (p.x_old < x_grid_stop && x_grid_stop <= p.x) {
+    double gyro_tmp;
+    if (h.custom_epsB && p.x > x_grid_stop) gyro_tmp = __builtin_sqrt(x_grid_stop / p.x); else gyro_tmp = 1.0;
+    const double grt = p.ptot_pf * CC_ * gyro_tmp / (MCS_QCGS * P.bmag2);
+    const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
+    p.prp = p.x + 3 * L_diff;
+  } else if (p.x_old < p.prp && p.x >= p.prp) {
+    const double vt = p.ptot_pf / (p.gam_pf * aa * MP_);
+    const double q = (vt - u2) / (vt + u2);
+    const double prob_ret = q * q;
+    if (vt < u2 || rng.rand() > prob_ret) {
+      p.i_return = 0;
+    } else {
+      p.i_return = 1;
+      Retro r;
+      r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+      r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = p.tcut_next; r.tcut = p.tcut;
+      r.n_retro = p.n_retro; r.rng_n = rng.n; r.rng_spare = rng.spare; r.lose_pt = false;
+      r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
+      p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut_next = r.tcut_next; p.tcut = r.tcut;
+      p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
+      if (lose_pt) p.i_return = 0;
+      p.x = p.prp;
+    }
+  } else {
+    if (aa < 1 && p.ptot_pf < a->pcut_prev && p.helix % 1000 == 0) {
+      const double grt = p.ptot_pf * CC_ * p.gyro_denom;
+      const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
+      if (p.x > 2.0e3 * L_diff) {
+        p.prp = 0.8 * p.x;
+      } else {
+        const double r = a->pcut_prev / p.ptot_pf;
+        const double r2 = r * r;
+        const double alt = x_grid_stop + L_diff * (r2 * r2 * r);
+        p.prp = p.prp < alt ? p.prp : alt;
+      }
+    }
   }
 }
 
@@ -635,65 +676,96 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   rng.k0 = (uint32_t)key; rng.k1 = (uint32_t)(key >> 32); rng.n = 0; rng.spare = 0.0;
 
   p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
-  p.gyro_denom = s.gd[p.i_grid];
+  p.gyro_denom = S_gd[p.i_grid];
   if (h.custom_epsB && p.x > h.x_grid_stop) p.gyro_denom *= __builtin_sqrt(p.x / h.x_grid_stop);
   p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
   p.gyro_period = TWOPI_ * p.gam_pf * h.m * CC_ * p.gyro_denom;
   p.i_return = -1;
   p.t_step = 0.0;
+  p.gp_key = -1.0;                       // forces the first t_step = gyro_period / xn_per
+  p.dphi = TWOPI_ / p.xn_per;
   p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
-  p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? s.tc[p.tcut - 1] : __builtin_inf();
+  p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? S_tc[p.tcut - 1] : __builtin_inf();
   p.cm_grt = -1.0; p.cm_xn = -1.0; p.cm_val = 0.0;
+  p.rp_key = -1.0; p.rp_val = 0.0; p.rg_key = -1.0; p.rg_val = 0.0;
 }
 
-// One pass of the helix loop (src/particle_loop.jl:154-499).  Returns -1 while the
-// particle lives, else the end code: 0 = saved for the next pcut, 1..4 = i_reason.
-__device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p) {
+// ------------------------------------------------------------------------------------------
+// One pass of the helix loop (src/particle_loop.jl:154-499), organised for the hardware:
+//   phase A  rare work BEFORE the scatter (helix cap, Code Block 1 after a PRP return, zone
+//            change: field/gyro reload, transform_p_PSP, energy transfer);
+//   phase B  the common step as straight-line code: escape compares, scattering, clock,
+//            pcut test, move, same-zone test (selects, no rare work, no memory waits);
+//   phase C  rare work AFTER the move (time-cut tally, no-DSA reflection, shock crossing,
+//            zone search + flux/PSD tallies, downstream test, PRP logic, retro walk).
+// Each rare item is behind a per-lane flag, so a wave only enters the code some lane needs.
+// The arithmetic and its order are those of the reference; only the control flow differs.
+// Returns -1 while the particle lives, else 0 = saved for the next pcut, 1..4 = i_reason.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p) {
   const double aa = h.aa;
+  int end = -1;
   p.helix += 1;
-  if (p.helix > MCS_HELIX_CAP) { cnt(a, MCS_IC_HELIX_CAP); return 1; }
 
-  if (p.i_return == 1) {
-    p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
-    p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-  } else {
-    // ---- Code Block 3
-    const int ig = p.i_grid, io = p.ig3;
-    p.ig3 = ig;
-    double bmag = 0.0;
-    if (h.custom_epsB && p.x > h.x_grid_stop) {
-      bmag = s.bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-      p.gyro_denom = 1 / (h.zzq * bmag);
-    } else {
-      p.gyro_denom = s.gd[ig];            // == 1/(zz*btot[ig]), tabulated per zone
+  // ================= phase A =================
+  const bool block1 = p.i_return == 1;
+  {
+    const bool capped = p.helix > MCS_HELIX_CAP;
+    const bool zone_ev = !block1 && (p.i_grid != p.ig3 || h.custom_epsB);
+    const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
+    if (capped | block1 | zone_ev | etf_ev) {
+      if (capped) {
+        cnt(a, MCS_IC_HELIX_CAP);
+        end = 1;                                                      // quirk Q5
+      } else if (block1) {
+        // Code Block 1 (particle_loop.jl:167-177)
+        p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
+        p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+      } else {
+        // rare head of Code Block 3 (particle_loop.jl:186-246)
+        const int ig = p.i_grid, io = p.ig3;
+        p.ig3 = ig;
+        if (h.custom_epsB && p.x > h.x_grid_stop) {
+          const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+          p.gyro_denom = 1 / (h.zzq * bmag);
+        } else {
+          p.gyro_denom = S_gd[ig];            // == 1/(zz*btot[ig]), tabulated per zone
+        }
+        if (ig != io && S_ux[ig] != S_ux[io]) {   // same zone => same u_x: no transform
+          const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
+          p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
+          p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+          p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+        }
+        if (etf_ev) {
+          Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+          r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
+          p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
+        }
+      }
     }
-    if (ig != io && s.ux[ig] != s.ux[io]) {   // same zone => same u_x: no transform
-      const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
-      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
-      p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-      p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
-    }
-    if (h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid) {
-      Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
-      r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
-      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
-    }
+  }
 
+  bool ev_tcut = false;
+  if (end < 0 && !block1) {
+    // ================= phase B, Code Block 3 (particle_loop.jl:251-385) =================
+    const int ig = p.ig3;
     if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
-    if (p.ptot_pf > h.pmax_cutoff) {
+    if (p.ptot_pf > h.pmax_cutoff) {        // rare (only near p_max); after the transforms of phase A
       double ptot_sk, px, py, pz, gam_sk;
-      transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, s.ux[ig], s.gsf[ig], s.bcos[ig], s.bsin[ig], ptot_sk, px, py, pz, gam_sk);
+      transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
       if (ptot_sk > h.pmax_cutoff) return 2;
     }
     if (p.inj && p.x < h.feb_up) return 2;
     if (h.age_max > 0 && p.acctime > h.age_max) return 3;
 
     if (h.rad_losses && aa < 1) {
-      if (!(h.custom_epsB && p.x > h.x_grid_stop)) bmag = s.bt[ig];
+      double bmag = S_bt[ig];
+      if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
       const double ptot_old = p.ptot_pf;
-      const double B_CMB_loc = a->P.B_CMBz * s.gef[ig];
+      const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
       p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, p.t_step);
       if (p.ptot_pf <= 0) {
         p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
@@ -706,87 +778,133 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, Rng
       p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
     }
 
-    if (!h.dont_scatter) scattering(a, rng, p, aa, aa * MP_ * CC_, h.eta);
+    if (!h.dont_scatter) scattering(a, rng, p, aa, aa * MP_ * CC_, h.eta, kc);
 
     if (p.downstream) {
-      p.acctime += p.t_step * s.gef[ig];
-      if (h.do_tcuts) tcut_check(a, s, p, h.n_tcuts);
-      if (p.ptot_pf > h.pcut) return 0;   // saved for the next pcut (particle_loop.jl:361-380)
+      p.acctime += p.t_step * S_gef[ig];
+      if (h.do_tcuts) {
+        // tcut_track! (cuts.jl:149-162) reads weight and ptot_pf, which the move does not change:
+        // the tally itself is deferred to phase C
+        if (p.tcut > h.n_tcuts) cnt(a, MCS_IC_TCUT_OVERRUN);   // D4
+        else ev_tcut = p.acctime >= p.tcut_next;
+      }
+      if (p.ptot_pf > h.pcut) end = 0;   // saved for the next pcut (particle_loop.jl:361-380): no move
     }
-    p.xn_per = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
+    if (end < 0) {
+      const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
+      if (xn != p.xn_per) { p.xn_per = xn; p.dphi = TWOPI_ / xn; p.gp_key = -1.0; }
+    }
   }
 
-  // ---- Code Block 2
+  // the saved particle's time-cut tally still has to happen (it precedes the save in the reference)
+  if (end == 0) {
+    if (ev_tcut) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
+    return 0;
+  }
+  if (end > 0) return end;
+
+  // ================= phase B, Code Block 2: the move (particle_loop.jl:392-407, 510-571) =================
   const int ig3 = p.ig3;
-  const double gsf = s.gsf[ig3], bcos = s.bcos[ig3], bsin = s.bsin[ig3], ux = s.ux[ig3];
+  const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
   p.x_old = p.x;
   const double phi_old = p.phi;
-  p.t_step = p.gyro_period / p.xn_per;
-  // no_DSA_loop (particle_loop.jl:510-571)
+  if (p.gyro_period != p.gp_key) { p.t_step = p.gyro_period / p.xn_per; p.gp_key = p.gyro_period; }
+  bool ev_reflect;
   {
     const double m = aa * MP_;
-    while (true) {
-      p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
-      const double x_move = p.pb_pf * p.t_step / (p.gam_pf * m);
-      double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
-      if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
-      const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
-      p.x = p.x_old + dx;
-      if (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1)) {
+    p.phi = mcsm::mod2pi(p.phi + p.dphi);
+    const double gm = p.gam_pf * m;
+    if (p.gam_pf != p.rg_key) { p.rg_val = rcp_refined(gm); p.rg_key = p.gam_pf; }
+    const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
+    double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
+    if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+    const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
+    p.x = p.x_old + dx;
+    ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1);
+  }
+  // same-zone test (all_flux.jl:64-82): one boundary compare in the common case
+  p.i_grid_old = p.i_grid;
+  const bool fwd = p.x > p.x_old;
+  const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
+  const bool ev_shock = p.x_old < 0 && p.x >= 0;
+  const bool ev_flux = !same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0;
+  const bool ev_dtest = (h.feb_down > 0 && p.x > h.feb_down) || p.x > 1.1 * p.prp;
+  const bool ev_prp = p.x >= h.x_grid_stop &&
+                      (p.x_old < h.x_grid_stop || (p.x_old < p.prp && p.x >= p.prp) || aa < 1);
+  if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
+  p.i_return = 2;                                             // prob_return's default (prob_return.jl:48)
+
+  // ================= phase C =================
+  if (ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp) {
+    if (ev_tcut) {
+      tcut_track(a, p.tcut, p.weight, p.ptot_pf);
+      p.tcut += 1;
+      p.tcut_next = p.tcut <= h.n_tcuts ? S_tc[p.tcut - 1] : __builtin_inf();
+    }
+    if (ev_reflect) {
+      // the retry loop of no_DSA_loop (particle_loop.jl:555-568); its first pass is the move above
+      const double m = aa * MP_;
+      while (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1)) {
         if (h.dont_DSA || (rng.rand() > h.inj_frac)) {
           if (p.pb_pf < 0) p.pb_pf = -p.pb_pf; else p.phi = rng.rand() * TWOPI_;
         } else break;
-      } else break;
+        p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
+        const double x_move = p.pb_pf * p.t_step / (p.gam_pf * m);
+        double gyr = 0.0;
+        if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+        const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
+        p.x = p.x_old + dx;
+      }
     }
-  }
-  if (p.x_old < 0 && p.x >= 0) {
-    p.downstream = true;
-    const double L_diff = h.eta / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * h.u2);
-    p.prp = p.prp > L_diff ? p.prp : L_diff;
-  }
-  if (p.downstream && p.x < 0) p.inj = true;
-
-  // all_flux! (all_flux.jl:45-82): zone search; tallies only when something was crossed
-  {
-    p.i_grid_old = p.i_grid;
-    const int ne = h.n_grid + 2;
-    int found = -1;
-    if (p.x > p.x_old) {
-      for (int j = p.i_grid + 1; j < ne; ++j) if (s.x[j] > p.x) { found = j - 1; break; }
-    } else {
-      for (int j = p.i_grid; j >= 0; --j) if (s.x[j] <= p.x) { found = j; break; }
+    if (ev_shock || ev_reflect) {
+      if (p.x_old < 0 && p.x >= 0) {          // particle_loop.jl:412-429
+        p.downstream = true;
+        const double L_diff = h.eta / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * h.u2);
+        p.prp = p.prp > L_diff ? p.prp : L_diff;
+      }
+      if (p.downstream && p.x < 0) p.inj = true;
     }
-    if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
-    p.i_grid = found;
-    if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0))
-      flux_tally(a, s, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, ig3, p.inj);
-  }
-
-  // downstream_test (particle_loop.jl:595-637)
-  bool do_prob_ret = true;
-  if (h.feb_down > 0 && p.x > h.feb_down) {
-    p.i_return = 0; do_prob_ret = false;
-  } else if (p.x > 1.1 * p.prp) {
-    const double m = aa * MP_;
-    double v_fac;
-    if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
-      const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
-      v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
-    } else {
-      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
+    if (ev_flux || ev_reflect) {
+      // all_flux! (all_flux.jl:45-82): zone search; tallies only when something was crossed
+      const int ne = h.n_grid + 2;
+      int found = -1;
+      if (p.x > p.x_old) {
+        for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { found = j - 1; break; }
+      } else {
+        for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { found = j; break; }
+      }
+      if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
+      p.i_grid = found;
+      if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0))
+        flux_tally(a, s, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, ig3, p.inj);
     }
-    const double L_diff = h.eta / 3 * v_fac;
-    if (p.x > 6.91 * L_diff) { p.i_return = 0; do_prob_ret = false; }
-  }
-  bool lose_pt = false;
-  if (do_prob_ret) prob_return(a, s, h, rng, p, lose_pt);
+    // downstream_test (particle_loop.jl:595-637) and prob_return; after a reflection or a
+    // shock crossing x and prp may have changed, so the tests are redone from scratch
+    bool do_prob_ret = true;
+    if (h.feb_down > 0 && p.x > h.feb_down) {
+      p.i_return = 0; do_prob_ret = false;
+    } else if (p.x > 1.1 * p.prp) {
+      const double m = aa * MP_;
+      double v_fac;
+      if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
+        const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
+        v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
+      } else {
+        v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
+      }
+      const double L_diff = h.eta / 3 * v_fac;
+      if (p.x > 6.91 * L_diff) { p.i_return = 0; do_prob_ret = false; }
+    }
+    bool lose_pt = false;
+    if (do_prob_ret) prob_return_events(a, s, h, rng, p, lose_pt);
 
-  if (p.i_return == 0) {
-    double vel = p.ptot_pf / h.m;
-    if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
-    sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
-    sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
-    return lose_pt ? 4 : 1;
+    if (p.i_return == 0) {
+      double vel = p.ptot_pf / h.m;
+      if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
+      sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
+      sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
+      return lose_pt ? 4 : 1;
+    }
   }
   return -1;
 }
@@ -796,35 +914,28 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, Rng
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD)
 mcs_k_transport(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
-  extern __shared__ double smem[];
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
   Lds s;
-  s.x = smem; s.ux = s.x + ne; s.uz = s.ux + ne; s.ut = s.uz + ne; s.gsf = s.ut + ne; s.gef = s.gsf + ne;
-  s.bt = s.gef + ne; s.bsin = s.bt + ne; s.bcos = s.bsin + ne; s.gd = s.bcos + ne;
-  s.fl = s.gd + ne;
-  s.tc = s.fl + 3 * ng;
-  s.nc = (int*)(s.tc + ntc);
   for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    s.x[i] = a->tb.x_grid[i]; s.ux[i] = a->tb.ux[i]; s.uz[i] = a->tb.uz[i]; s.ut[i] = a->tb.utot[i];
-    s.gsf[i] = a->tb.gsf[i]; s.gef[i] = a->tb.gef[i];
+    S_x[i] = a->tb.x_grid[i]; S_ux[i] = a->tb.ux[i]; S_uz[i] = a->tb.uz[i]; S_ut[i] = a->tb.utot[i];
+    S_gsf[i] = a->tb.gsf[i]; S_gef[i] = a->tb.gef[i];
     const double bt = a->tb.btot[i], th = a->tb.theta[i];
-    s.bt[i] = bt;
+    S_bt[i] = bt;
     double sn, cs;
     mcsm::sincos(th, &sn, &cs);
-    s.bsin[i] = sn; s.bcos[i] = cs;
-    s.gd[i] = 1 / (a->zzq * bt);
+    S_bsin[i] = sn; S_bcos[i] = cs;
+    S_gd[i] = 1 / (a->zzq * bt);
   }
-  for (int i = threadIdx.x; i < 3 * ng; i += blockDim.x) s.fl[i] = 0.0;
-  for (int i = threadIdx.x; i < ntc; i += blockDim.x) s.tc[i] = a->tb.tcuts[i];
-  for (int i = threadIdx.x; i < ng; i += blockDim.x) s.nc[i] = 0;
+  for (int i = threadIdx.x; i < 3 * MCS_MAXNE; i += blockDim.x) S_fl[i] = 0.0;
+  for (int i = threadIdx.x; i < ntc; i += blockDim.x) S_tc[i] = a->tb.tcuts[i];
+  for (int i = threadIdx.x; i < MCS_MAXNE; i += blockDim.x) S_nc[i] = 0;
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
   if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
   __syncthreads();
 
   // Hot-loop constants are parked in VGPRs behind an opaque move: the compiler can then
-  // neither re-load them from the constant buffer inside the loop (s_load + s_waitcnt
-  // lgkmcnt(0): ~20 scalar loads per step were 85 % of a lone wave's cycles) nor spill them
-  // as SGPRs.  ~40 VGPRs, bought back by never waiting on memory in the loop.
+  // neither re-load them from the constant buffer inside the loop (s_load + s_waitcnt) nor
+  // spill them as SGPRs.
   Hot h;
   h.aa = vconst(a->aa); h.m = vconst(a->m); h.mc = vconst(a->mc); h.zzq = vconst(a->zzq); h.pcut = vconst(a->pcut);
   h.pmax_cutoff = vconst(a->pmax_cutoff);
@@ -832,14 +943,21 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   h.x_grid_stop = vconst(a->P.x_grid_stop); h.u2 = vconst(a->P.u2); h.eta = vconst(a->P.eta_mfp);
   h.xn_fine = vconst(a->P.xn_per_fine); h.xn_coarse = vconst(a->P.xn_per_coarse); h.inj_frac = vconst(a->inj_frac);
   h.n_grid = vconsti(ng); h.i_grid_feb = vconsti(a->P.i_grid_feb); h.n_tcuts = vconsti(ntc); h.n_xspec = vconsti(a->tb.n_xspec);
-  {
-    const int flags = (a->P.use_custom_epsB != 0 ? 1 : 0) | (a->P.energy_transfer_frac > 0 ? 2 : 0) |
-                      (a->P.dont_scatter != 0 ? 4 : 0) | (a->P.do_rad_losses != 0 ? 8 : 0) |
-                      (a->P.do_tcuts != 0 ? 16 : 0) | (a->P.dont_DSA != 0 ? 32 : 0);
-    const int fv = vconsti(flags);
-    h.custom_epsB = fv & 1; h.etf = fv & 2; h.dont_scatter = fv & 4; h.rad_losses = fv & 8; h.do_tcuts = fv & 16;
-    h.dont_DSA = fv & 32;
-  }
+  // uniform flags stay scalar (s_cbranch): whole code regions are skipped for free
+  h.custom_epsB = a->P.use_custom_epsB != 0; h.etf = a->P.energy_transfer_frac > 0;
+  h.dont_scatter = a->P.dont_scatter != 0; h.rad_losses = a->P.do_rad_losses != 0;
+  h.do_tcuts = a->P.do_tcuts != 0; h.dont_DSA = a->P.dont_DSA != 0;
+
+  // the 25 polynomial coefficients of the per-step sincos + asin, resident in VGPRs
+  mcsm::HotCoef kc;
+  kc.S0 = vconst(MCS_SIN_0); kc.S1 = vconst(MCS_SIN_1); kc.S2 = vconst(MCS_SIN_2); kc.S3 = vconst(MCS_SIN_3);
+  kc.S4 = vconst(MCS_SIN_4); kc.S5 = vconst(MCS_SIN_5);
+  kc.C0 = vconst(MCS_COS_0); kc.C1 = vconst(MCS_COS_1); kc.C2 = vconst(MCS_COS_2); kc.C3 = vconst(MCS_COS_3);
+  kc.C4 = vconst(MCS_COS_4); kc.C5 = vconst(MCS_COS_5);
+  kc.A0 = vconst(MCS_ASIN_0); kc.A1 = vconst(MCS_ASIN_1); kc.A2 = vconst(MCS_ASIN_2); kc.A3 = vconst(MCS_ASIN_3);
+  kc.A4 = vconst(MCS_ASIN_4); kc.A5 = vconst(MCS_ASIN_5); kc.A6 = vconst(MCS_ASIN_6); kc.A7 = vconst(MCS_ASIN_7);
+  kc.A8 = vconst(MCS_ASIN_8); kc.A9 = vconst(MCS_ASIN_9); kc.A10 = vconst(MCS_ASIN_10); kc.A11 = vconst(MCS_ASIN_11);
+  kc.A12 = vconst(MCS_ASIN_12);
 
   Pt p;
   Rng rng;
@@ -875,7 +993,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
       continue;
     }
     if (active) {
-      const int end = helix_step(a, s, h, rng, p);
+      const int end = helix_step(a, s, h, kc, rng, p);
       if (end >= 0) {
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
@@ -928,23 +1046,21 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     if (v != 0.0) gadd_f64(&a->T[off], v);
   }
   for (int i = threadIdx.x; i < ng; i += blockDim.x) {
-    const double v0 = s.fl[i], v1 = s.fl[ng + i], v2 = s.fl[2 * ng + i];
+    const double v0 = S_fl[i], v1 = S_fl[MCS_MAXNE + i], v2 = S_fl[2 * MCS_MAXNE + i];
     if (v0 != 0.0) gadd_f64(&a->T[a->L.pxx_flux + i], v0);
     if (v1 != 0.0) gadd_f64(&a->T[a->L.pxz_flux + i], v1);
     if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
-    const int c = s.nc[i];
+    const int c = S_nc[i];
     if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
   }
 }
 
-extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) {
-  const int ne = n_grid + 2;
-  return (size_t)(10 * ne + 3 * n_grid + n_tcuts) * sizeof(double) + (size_t)n_grid * sizeof(int);
-}
+extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_grid; (void)n_tcuts; return 0; }   // static LDS
+extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 
 // `a_dev`: device copy of the launch constants (written by the caller on `st`).
 extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st) {
-  const size_t sm = mcs_transport_smem_bytes(n_grid, n_tcuts);
-  hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), sm, st, a_dev);
+  (void)n_grid; (void)n_tcuts;
+  hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
   return hipGetLastError();
 }
