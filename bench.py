@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--cpu-sample", type=int, default=60000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -135,6 +135,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    traffic = None
+    try:   # HBM bytes per K1 launch from the committed PMC passes (tools/profile_bench.sh)
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         value = steps_total / elapsed
         local_steps = steps_total / world          # shards are balanced by construction
@@ -152,8 +158,8 @@ def main():
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"particle shards x{world}, all-gather(n_saved)/pcut, all-reduce(tallies)/iter"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "mcs_k_transport", "launches": n_launch,
+                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "mcs_k_transport (+ mcs_k_flux_events, its deferred tallies)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                          "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "
