@@ -242,8 +242,6 @@ int mcs_final_download(mcs_ctx* ctx, int64_t n, int32_t* reason, int32_t* helix_
                        int32_t* retro_count, double* ptot_pf, double* x_PT_cm);
 /* kernel time [ms] of the last mcs_run_pcut, from HIP events on the context stream */
 double mcs_last_kernel_ms(mcs_ctx* ctx);
-/* part of it spent in the deferred zone-crossing tally kernel (K1b) */
-double mcs_last_tally_ms(mcs_ctx* ctx);
 /* launch geometry override: blocks (0 = auto), threads per block (0 = auto) */
 int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
 

@@ -211,7 +211,6 @@ def load_library() -> ct.CDLL:
         "mcs_eval_fn": (i32, [vp, i32, i64, c_double_p, c_double_p, c_double_p]),
         "mcs_final_download": (i32, [vp, i64, c_int32_p, c_int32_p, c_int32_p, c_double_p, c_double_p]),
         "mcs_last_kernel_ms": (dbl, [vp]),
-        "mcs_last_tally_ms": (dbl, [vp]),
         "mcs_set_launch": (i32, [vp, i32, i32]),
         "mcs_get_layout": (i32, [ct.POINTER(McsParams), c_int64_p]),
     }
@@ -228,6 +227,6 @@ EXPORTED_SYMBOLS = [
     "mcs_tallies_f64_devptr", "mcs_tallies_i64_devptr", "mcs_set_grid", "mcs_set_cuts", "mcs_begin_iteration",
     "mcs_begin_species", "mcs_set_fluxes", "mcs_pop_upload", "mcs_pop_download", "mcs_saved_download",
     "mcs_pop_size", "mcs_init_pop", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
-    "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_last_tally_ms", "mcs_set_launch",
+    "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout",
 ]

@@ -18,7 +18,6 @@ extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st);
-hipError_t mcs_launch_flux_events(const KArgs* a_dev, int n_waves, hipStream_t st);
 hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
                                unsigned int* block_counts, unsigned long long* block_offsets,
                                unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st);
@@ -75,11 +74,6 @@ struct mcs_ctx {
   double* d_stage = nullptr; long long stage_cap = 0;
   // launch constants: host copy (stable address for the async upload) and device copy
   KArgs h_args; KArgs* d_args = nullptr;
-  // deferred zone-crossing tally records (one segment per wave of the transport launch)
-  double* d_ev_f64 = nullptr; uint32_t* d_ev_u32 = nullptr; unsigned int* d_ev_count = nullptr;
-  long long ev_cap_total = 0; int ev_waves_cap = 0;
-  double events_per_particle = 192.0;   // sizing of the record buffer; 0 = tally inline
-  hipEvent_t ev2 = nullptr; double last_tally_ms = 0.0;
   // species
   int i_iter = 1, i_ion = 1;
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
@@ -233,8 +227,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipMemsetAsync(c->d_I, 0, (size_t)mcs_i64_total(p) * sizeof(unsigned long long), c->stream));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
-  HIPCHK(hipEventCreate(&c->ev2));
-  if (const char* e = getenv("MCS_EVENTS_PER_PARTICLE")) c->events_per_particle = atof(e);
+
   HIPCHK(hipStreamSynchronize(c->stream));
   *out = c;
   return 0;
@@ -246,13 +239,12 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_ev_f64, c->d_ev_u32, c->d_ev_count};
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->ev2) (void)hipEventDestroy(c->ev2);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -464,48 +456,16 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
     blocks = (int)(want < full ? want : full);
     if (blocks < 1) blocks = 1;
   }
-  // event-record buffer: one segment per wave of this launch
-  a.seg_cap = 0; a.n_waves = blocks * (threads / 64);
-  if (c->events_per_particle > 0 && n > 0) {
-    long long want = (long long)(c->events_per_particle * (double)n) + 4096LL * a.n_waves;
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const long long rec_bytes = MCS_EV_F64 * 8 + 4;
-    if (want > c->ev_cap_total) {
-      long long lim = (long long)((double)(free_b + (size_t)c->ev_cap_total * rec_bytes) * 0.6 / rec_bytes);
-      long long cap = want < lim ? want : lim;
-      if (cap > c->ev_cap_total) {
-        if (c->d_ev_f64) { (void)hipFree(c->d_ev_f64); (void)hipFree(c->d_ev_u32); c->d_ev_f64 = nullptr; c->d_ev_u32 = nullptr; }
-        HIPCHK(hipMalloc((void**)&c->d_ev_f64, (size_t)cap * MCS_EV_F64 * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&c->d_ev_u32, (size_t)cap * sizeof(uint32_t)));
-        c->ev_cap_total = cap;
-      }
-    }
-    if (a.n_waves > c->ev_waves_cap) {
-      if (c->d_ev_count) (void)hipFree(c->d_ev_count);
-      HIPCHK(hipMalloc((void**)&c->d_ev_count, (size_t)a.n_waves * sizeof(unsigned int)));
-      c->ev_waves_cap = a.n_waves;
-    }
-    const long long use = want < c->ev_cap_total ? want : c->ev_cap_total;
-    a.seg_cap = use / a.n_waves;
-    if (a.seg_cap > 0x7fffffffLL) a.seg_cap = 0x7fffffffLL;
-    a.ev_f64 = c->d_ev_f64; a.ev_u32 = c->d_ev_u32; a.ev_count = c->d_ev_count;
-    HIPCHK(hipMemsetAsync(c->d_ev_count, 0, (size_t)a.n_waves * sizeof(unsigned int), c->stream));
-  }
   HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
   if (n > 0) HIPCHK(mcs_launch_transport(c->d_args, c->P.n_grid, c->tb.n_tcuts, blocks, threads, c->stream));
   HIPCHK(hipEventRecord(c->ev1, c->stream));
-  if (n > 0 && a.seg_cap > 0) HIPCHK(mcs_launch_flux_events(c->d_args, a.n_waves, c->stream));
-  HIPCHK(hipEventRecord(c->ev2, c->stream));
   unsigned long long ns = 0;
   HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev2));     // K1 transport + K1b deferred tallies
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_ms = ms;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev1, c->ev2));
-  c->last_tally_ms = ms;
   c->n_saved_last = (long long)ns;
   if (n_saved) *n_saved = (int64_t)ns;
   return 0;
@@ -580,6 +540,5 @@ int mcs_final_download(mcs_ctx* c, int64_t n, int32_t* reason, int32_t* helix_co
 }
 
 double mcs_last_kernel_ms(mcs_ctx* c) { return c->last_ms; }
-double mcs_last_tally_ms(mcs_ctx* c) { return c->last_tally_ms; }
 
 }  // extern "C"

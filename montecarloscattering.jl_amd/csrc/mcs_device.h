@@ -46,16 +46,10 @@ struct KArgs {
   unsigned long long* n_saved;
   int32_t *f_reason, *f_helix, *f_retro;
   double *f_ptot, *f_x;
-  // Deferred zone-crossing tallies: every wave owns one segment of the event buffer and
-  // appends a record per all_flux! call that has something to tally (no atomics: the
-  // cursor is wave-private); mcs_k_flux_events then tallies all records with full waves.
-  double* ev_f64;            // [n_waves][MCS_EV_F64][seg_cap]
-  uint32_t* ev_u32;          // [n_waves][seg_cap]
-  unsigned int* ev_count;    // [n_waves] records written by each wave
-  long long seg_cap;         // records per wave segment (0: tally inline)
-  int n_waves;
 };
 
+// zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old
+#define MCS_EV_CAP 128       // records per wave (drained 64 at a time)
 
 #endif

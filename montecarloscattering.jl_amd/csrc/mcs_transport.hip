@@ -146,7 +146,14 @@ __shared__ double S_x[MCS_MAXNE], S_ux[MCS_MAXNE], S_uz[MCS_MAXNE], S_ut[MCS_MAX
 __shared__ double S_fl[3 * MCS_MAXNE];      // pxx | pxz | energy flux staging, stride MCS_MAXNE
 __shared__ double S_tc[MCS_NA_C];           // time cuts
 __shared__ int S_nc[MCS_MAXNE];             // num_crossings staging
-__shared__ unsigned int S_evcur[4];         // per-wave cursor into its event segment
+// Deferred zone-crossing tallies: a lane that crossed a zone boundary does NOT run the
+// ~300-instruction tally code (transform, bins, atomics) on the spot -- with a handful of
+// active lanes while the rest of the wave waits, that cost 43 % of the kernel.  It pushes a
+// record into its wave's LDS stack; whenever 64 records are pending the whole wave pops 64
+// and tallies them, one record per lane (the tallies do not feed back into the particles).
+__shared__ double S_evf[4][MCS_EV_F64][MCS_EV_CAP];
+__shared__ unsigned int S_evu[4][MCS_EV_CAP];
+__shared__ unsigned int S_evcur[4];         // per-wave stack height
 struct Lds {                                // kept as an (empty) handle so call sites read the same
   static constexpr double* x = nullptr;
 };
@@ -877,31 +884,17 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
       if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) {
-        // Tallies do not feed back into the particle: append a record to this wave's event
-        // segment and let mcs_k_flux_events do the transform, the bins and the atomics with
-        // full waves (inline they cost 43 % of the kernel: a few lanes execute ~300
-        // instructions while the other lanes of the wave wait).
-        bool pushed = false;
-        if (a->seg_cap > 0) {
-          const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
-          const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-          const unsigned base = S_evcur[wv];
-          const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
-          const unsigned n_ev = (unsigned)__popcll(m_ev);
-          if ((long long)(base + n_ev) <= a->seg_cap) {
-            const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + wv;
-            double* ef = a->ev_f64 + gw * (MCS_EV_F64 * a->seg_cap) + pos;
-            const long long sc = a->seg_cap;
-            ef[0] = p.pb_pf; ef[sc] = p.p_perp; ef[2 * sc] = p.ptot_pf; ef[3 * sc] = p.gam_pf; ef[4 * sc] = p.phi;
-            ef[5 * sc] = p.weight; ef[6 * sc] = p.x; ef[7 * sc] = p.x_old;
-            a->ev_u32[gw * sc + pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) |
-                                       ((uint32_t)(p.inj ? 1u : 0u) << 24);
-            if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + n_ev;
-            pushed = true;
-          }
-        }
-        if (!pushed)   // segment full (or deferral off): tally right here
-          flux_tally(a, s, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, ig3, p.inj);
+        // Tallies do not feed back into the particle: push a record (see S_evf).  The stack
+        // cannot overflow: it is drained to < 64 at the top of every pass and one pass adds
+        // at most one record per lane.
+        const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
+        const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+        const unsigned base = S_evcur[wv];
+        const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
+        S_evf[wv][0][pos] = p.pb_pf; S_evf[wv][1][pos] = p.p_perp; S_evf[wv][2][pos] = p.ptot_pf; S_evf[wv][3][pos] = p.gam_pf;
+        S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
+        S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
+        if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
       }
     }
     // downstream_test (particle_loop.jl:595-637) and prob_return; after a reflection or a
@@ -936,6 +929,24 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
 }
 
 }  // namespace
+
+// Pop up to 64 records from this wave's stack and tally them, one per lane (convergent code).
+__device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, unsigned lane, bool all) {
+  unsigned cnt = S_evcur[wv];
+  while (cnt >= 64u || (all && cnt > 0u)) {
+    const unsigned take = cnt < 64u ? cnt : 64u;
+    const unsigned base = cnt - take;
+    if (lane < take) {
+      const unsigned e = base + lane;
+      const uint32_t u = S_evu[wv][e];
+      flux_tally(a, s, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
+                 S_evf[wv][6][e], S_evf[wv][7][e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu),
+                 ((u >> 24) & 1u) != 0u);
+    }
+    cnt = base;
+  }
+  if (lane == 0) S_evcur[wv] = cnt;
+}
 
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD)
 mcs_k_transport(const KArgs* __restrict__ ka) {
@@ -994,7 +1005,9 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   const unsigned lane = __lane_id();
   const unsigned long long n = (unsigned long long)a->n;
 
+  const unsigned wv = threadIdx.x >> 6;
   for (;;) {
+    if (S_evcur[wv] >= 64u) drain_events(a, s, wv, lane, false);   // wave-uniform
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
     if (idle != 0ull && !exhausted) {
@@ -1050,8 +1063,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     c_retro += __shfl_down(c_retro, off);
     c_draws += __shfl_down(c_draws, off);
   }
-  if (lane == 0 && a->seg_cap > 0)
-    a->ev_count[(long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = S_evcur[threadIdx.x >> 6];
+  drain_events(a, s, wv, lane, true);
   if (lane == 0) {   // 64-bit totals go straight to the global counters (one atomic per wave)
     if (c_helix) gadd_u64(&a->I[ng + MCS_IC_STEPS_HELIX], c_helix);
     if (c_retro) gadd_u64(&a->I[ng + MCS_IC_STEPS_RETRO], c_retro);
@@ -1082,61 +1094,6 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     const int c = S_nc[i];
     if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
   }
-}
-
-// K1b: tally the deferred zone-crossing records (all_flux.jl:84-161, F_stream!) with full
-// waves.  One workgroup per wave segment; same LDS tables and staging as the transport kernel.
-extern "C" __global__ void __launch_bounds__(256)
-mcs_k_flux_events(const KArgs* __restrict__ ka) {
-  CK* a = (CK*)ka;
-  const int ne = a->P.n_grid + 2, ng = a->P.n_grid;
-  Lds s;
-  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    S_x[i] = a->tb.x_grid[i]; S_ux[i] = a->tb.ux[i]; S_gsf[i] = a->tb.gsf[i];
-    double sn, cs;
-    mcsm::sincos(a->tb.theta[i], &sn, &cs);
-    S_bsin[i] = sn; S_bcos[i] = cs;
-  }
-  for (int i = threadIdx.x; i < 3 * MCS_MAXNE; i += blockDim.x) S_fl[i] = 0.0;
-  for (int i = threadIdx.x; i < MCS_MAXNE; i += blockDim.x) S_nc[i] = 0;
-  if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
-  if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
-  __syncthreads();
-  const long long sc = a->seg_cap;
-  for (long long w = blockIdx.x; w < a->n_waves; w += gridDim.x) {
-    const unsigned n_ev = a->ev_count[w];
-    const double* ef = a->ev_f64 + w * (MCS_EV_F64 * sc);
-    const uint32_t* eu = a->ev_u32 + w * sc;
-    for (unsigned e = threadIdx.x; e < n_ev; e += blockDim.x) {
-      const uint32_t u = eu[e];
-      flux_tally(a, s, ef[e], ef[sc + e], ef[2 * sc + e], ef[3 * sc + e], ef[4 * sc + e], ef[5 * sc + e], ef[6 * sc + e],
-                 ef[7 * sc + e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu), ((u >> 24) & 1u) != 0u);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < MCS_IC_COUNT) {
-    const unsigned int c = g_ctr[threadIdx.x];
-    if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
-  } else if (threadIdx.x > MCS_IC_COUNT && threadIdx.x < MCS_IC_COUNT + 5) {
-    const int j = threadIdx.x - MCS_IC_COUNT - 1;
-    const double v = g_sc[j];
-    if (v != 0.0) gadd_f64(&a->T[a->L.scalars + j], v);
-  }
-  for (int i = threadIdx.x; i < ng; i += blockDim.x) {
-    const double v0 = S_fl[i], v1 = S_fl[MCS_MAXNE + i], v2 = S_fl[2 * MCS_MAXNE + i];
-    if (v0 != 0.0) gadd_f64(&a->T[a->L.pxx_flux + i], v0);
-    if (v1 != 0.0) gadd_f64(&a->T[a->L.pxz_flux + i], v1);
-    if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
-    const int c = S_nc[i];
-    if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
-  }
-}
-
-extern "C" hipError_t mcs_launch_flux_events(const KArgs* a_dev, int n_waves, hipStream_t st) {
-  int blocks = n_waves < 2048 ? n_waves : 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mcs_k_flux_events, dim3(blocks), dim3(256), 0, st, a_dev);
-  return hipGetLastError();
 }
 
 extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_grid; (void)n_tcuts; return 0; }   // static LDS

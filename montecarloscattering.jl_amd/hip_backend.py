@@ -147,9 +147,6 @@ class HipBackend:
     def last_kernel_ms(self) -> float:
         return float(self.lib.mcs_last_kernel_ms(self.h))
 
-    def last_tally_ms(self) -> float:
-        return float(self.lib.mcs_last_tally_ms(self.h))
-
     def eval_fn(self, name: str, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)

@@ -101,16 +101,6 @@ def test_custom_epsB_flag_and_downstream_feb():
     _lockstep(prob, N, 8)
 
 
-def test_event_buffer_overflow_falls_back_to_inline_tallies(monkeypatch):
-    """The zone-crossing tallies are normally deferred to per-wave record segments; with a
-    deliberately tiny buffer most of them take the inline path.  Same results either way."""
-    monkeypatch.setenv("MCS_EVENTS_PER_PARTICLE", "2")
-    N = 2500
-    _lockstep(make_problem(N), N, 8)
-    monkeypatch.setenv("MCS_EVENTS_PER_PARTICLE", "0")      # deferral off: everything inline
-    _lockstep(make_problem(N), N, 6)
-
-
 def test_host_buffer_drop_in_call():
     """mcs_run_pcut_host(in, saved_out, l_save): the literal replacement of the loop at
     src/main_loops.jl:228-292 gives the same arrays as the resident path."""
