@@ -97,7 +97,7 @@ def main():
     n_itrs = args.steps + args.warmup
     cfg = mcs.inputs.Config(N_PTS_INJ=n_global, N_PTS_PCUT=n_global, N_PTS_PCUT_HI=n_global, num_iterations=n_itrs)
     prob = mcs.inputs.build_problem(cfg)
-    be = hip_backend.HipBackend(local)
+    be = hip_backend.HipBackend(local, torch_tallies=world > 1)
     be.create(prob)
     comm = mcs.driver.Comm(world > 1, dev)
 

@@ -173,6 +173,7 @@ struct Pt {
   double cm_grt, cm_xn, cm_val;  // cache of cos_max for (gyro_rad_tot, xn_per) (scattering.jl:60)
   int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
   bool downstream, inj;
+  bool pushed;                   // this lane pushed a tally record in the current pass
 };
 
 // Tally atomics with the address space spelled out, so that the ISA is
@@ -698,6 +699,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? S_tc[p.tcut - 1] : __builtin_inf();
   p.cm_grt = -1.0; p.cm_xn = -1.0; p.cm_val = 0.0;
   p.rp_key = -1.0; p.rp_val = 0.0; p.rg_key = -1.0; p.rg_val = 0.0;
+  p.pushed = false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -895,6 +897,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
         S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
         S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
         if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
+        p.pushed = true;
       }
     }
     // downstream_test (particle_loop.jl:595-637) and prob_return; after a reflection or a
@@ -1006,8 +1009,12 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   const unsigned long long n = (unsigned long long)a->n;
 
   const unsigned wv = threadIdx.x >> 6;
+  unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
+  p.pushed = false;
   for (;;) {
-    if (S_evcur[wv] >= 64u) drain_events(a, s, wv, lane, false);   // wave-uniform
+    ev_pending += (unsigned)__popcll(__ballot(p.pushed));
+    p.pushed = false;
+    if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; }
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
     if (idle != 0ull && !exhausted) {

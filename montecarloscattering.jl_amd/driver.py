@@ -64,7 +64,9 @@ class Comm:
         if not self.enabled:
             return [int(v)]
         import torch
-        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        # NCCL/RCCL needs device tensors; gloo gathers on the host
+        dev = self.device if self.dist.get_backend() == "nccl" else None
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
         out = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [int(o.item()) for o in out]
@@ -102,14 +104,27 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     per_species = []
     # rank > 0 keeps only its local partial sums: everything it contributes is a delta
     is_root = comm.rank == 0
+    multi = comm.world > 1
     G_f = G_i = None
+    # Live device tensors of the tallies (HIP backend with torch_tallies): the multi-GPU merge
+    # then runs in place on the device (RCCL all-reduce, no host round trip).  Otherwise
+    # (CPU test backends) the same steps go through read_tallies/write_tallies.
+    dev_t = backend.tally_tensors() if (multi and hasattr(backend, "tally_tensors")) else None
+    G_pool = None       # merged energy_transfer_pool of the previous species
+
+    def tview(t, name):
+        o = L.offsets[name]
+        return t[o:o + int(np.prod(L.shapes[name]))]
 
     for i_iter in range(1, n_itrs + 1):
         backend.begin_iteration(i_iter)
-        if not is_root:
-            f, i = backend.read_tallies()
-            f[:] = 0.0
-            backend.write_tallies(f, i)
+        if multi and not is_root:
+            if dev_t is not None:
+                dev_t[0].zero_()
+            else:
+                f, i = backend.read_tallies()
+                f[:] = 0.0
+                backend.write_tallies(f, i)
         for i_ion, sp in enumerate(cfg.species, start=1):
             pmax_cutoff = inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
             inj = inputs.init_pop_host(prob, i_ion)
@@ -118,14 +133,21 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             backend.begin_species(i_iter, i_ion, sp.aa, zz, pmax_cutoff, sp.density, ewf)
             if is_root:
                 backend.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
-            if comm.world > 1:
-                f, i = backend.read_tallies()
-                if not is_root:   # per-species fills are baselines too
-                    for name in ("psd", "esc_psd_up", "esc_psd_down"):
-                        L.view(f, name)[...] = 0.0
-                if G_f is not None:  # ions' donated energy, merged at the previous species end
-                    L.view(f, "energy_recv_pool")[...] = L.view(G_f, "energy_transfer_pool")
-                backend.write_tallies(f, i)
+            if multi:
+                if dev_t is not None:
+                    if not is_root:   # per-species fills are baselines too
+                        for name in ("psd", "esc_psd_up", "esc_psd_down"):
+                            tview(dev_t[0], name).zero_()
+                    if G_pool is not None:   # ions' donated energy, merged at the previous species end
+                        tview(dev_t[0], "energy_recv_pool").copy_(G_pool)
+                else:
+                    f, i = backend.read_tallies()
+                    if not is_root:
+                        for name in ("psd", "esc_psd_up", "esc_psd_down"):
+                            L.view(f, name)[...] = 0.0
+                    if G_pool is not None:
+                        L.view(f, "energy_recv_pool")[...] = G_pool
+                    backend.write_tallies(f, i)
 
             n_total = inj.n_pts_use
             lo, hi = shard_range(n_total, comm.rank, comm.world)
@@ -156,25 +178,31 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 n_use_global = n_saved * i_mult
 
             # species end: merge the partial tallies of all ranks (C1)
-            f, i = backend.read_tallies()
-            if comm.world > 1:
+            if multi and dev_t is not None:
+                tf, ti = dev_t
                 if not is_root:   # every rank carried a full copy of the received-energy pool
-                    L.view(f, "energy_recv_pool")[...] = 0.0
-                tf, ti = torch.from_numpy(f), torch.from_numpy(i)
-                if comm.device is not None and comm.device.type == "cuda":
-                    tf_d, ti_d = tf.to(comm.device), ti.to(comm.device)
-                    comm.all_reduce_sum_(tf_d); comm.all_reduce_sum_(ti_d)
-                    f, i = tf_d.cpu().numpy(), ti_d.cpu().numpy()
-                else:
-                    comm.all_reduce_sum_(tf); comm.all_reduce_sum_(ti)
-                G_f, G_i = f.copy(), i.copy()
-                if is_root:
-                    backend.write_tallies(G_f, G_i)
-                else:
-                    z = np.zeros_like(G_f)
-                    backend.write_tallies(z, np.zeros_like(G_i))
+                    tview(tf, "energy_recv_pool").zero_()
+                comm.all_reduce_sum_(tf)
+                comm.all_reduce_sum_(ti)
+                G_pool = tview(tf, "energy_transfer_pool").clone()
+                G_f, G_i = tf.cpu().numpy(), ti.cpu().numpy()
+                if not is_root:
+                    tf.zero_(); ti.zero_()
             else:
-                G_f, G_i = f, i
+                f, i = backend.read_tallies()
+                if multi:
+                    if not is_root:
+                        L.view(f, "energy_recv_pool")[...] = 0.0
+                    tf, ti = torch.from_numpy(f), torch.from_numpy(i)
+                    comm.all_reduce_sum_(tf); comm.all_reduce_sum_(ti)
+                    G_f, G_i = f.copy(), i.copy()
+                    G_pool = L.view(G_f, "energy_transfer_pool").copy()
+                    if is_root:
+                        backend.write_tallies(G_f, G_i)
+                    else:
+                        backend.write_tallies(np.zeros_like(G_f), np.zeros_like(G_i))
+                else:
+                    G_f, G_i = f, i
             per_species.append((i_iter, i_ion, G_f.copy(), G_i.copy()))
             if on_species_end is not None:
                 on_species_end(i_iter, i_ion, G_f, G_i)

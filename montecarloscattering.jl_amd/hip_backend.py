@@ -24,12 +24,15 @@ def _dp(a: np.ndarray):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, device: int = 0, stream: int = 0):
+    def __init__(self, device: int = 0, stream: int = 0, torch_tallies: bool = False):
+        """torch_tallies: keep the flat tally buffers in torch CUDA tensors on torch's current
+        stream, so that torch.distributed can all-reduce them in place (multi-GPU driver)."""
         self.lib = capi.load_library()          # raises MissingNativeLibrary
         if self.lib.mcs_abi_version() != capi.MCS_ABI_VERSION:
             raise RuntimeError("libmcs_hip.so ABI version mismatch")
         self.device = int(device)
         self.stream = int(stream)
+        self.torch_tallies = torch_tallies
         self.h = ct.c_void_p(None)
         self._bound = None
 
@@ -42,7 +45,16 @@ class HipBackend:
         self.prob = prob
         self.P = prob.params
         self.layout = capi.Layout(self.P)
+        if self.torch_tallies:
+            import torch
+            torch.cuda.set_device(self.device)
+            self.stream = int(torch.cuda.current_stream(self.device).cuda_stream)
         self._chk(self.lib.mcs_create(ct.byref(self.P), self.device, ct.c_void_p(self.stream or None), ct.byref(self.h)))
+        if self.torch_tallies:
+            dev = torch.device("cuda", self.device)
+            t_f = torch.zeros(self.layout.total, dtype=torch.float64, device=dev)
+            t_i = torch.zeros(self.layout.n_i64, dtype=torch.int64, device=dev)
+            self.bind_torch_tallies(t_f, t_i)
         tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in prob.grid_tables()]
         self._chk(self.lib.mcs_set_grid(self.h, len(tabs[0]), *[_dp(t) for t in tabs]))
         pc, tc, xs, inj, eps = (np.ascontiguousarray(a, dtype=np.float64) for a in
@@ -60,6 +72,10 @@ class HipBackend:
         self._bound = (t_f64, t_i64)
         self._chk(self.lib.mcs_bind_tallies(self.h, ct.c_void_p(t_f64.data_ptr()), t_f64.numel(),
                                             ct.c_void_p(t_i64.data_ptr()), t_i64.numel()))
+
+    def tally_tensors(self):
+        """Live device tensors (f64, i64) holding the tallies, or None when the context owns them."""
+        return self._bound
 
     def set_launch(self, blocks: int = 0, threads: int = 0):
         self._chk(self.lib.mcs_set_launch(self.h, blocks, threads))

@@ -16,7 +16,9 @@ def main():
     import _mcs_loader
     mcs = _mcs_loader.load()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo" if backend_kind == "oracle" else "nccl", rank=rank, world_size=world)
+    # "oracle": CPU oracle over gloo; "hip-gloo": HIP backend, all ranks on GPU 0, CUDA tensors over
+    # gloo (rehearses the device-side merge on a one-GPU box); "hip": one GPU per rank over RCCL
+    dist.init_process_group("nccl" if backend_kind == "hip" else "gloo", rank=rank, world_size=world)
     two_species = len(sys.argv) > 5 and sys.argv[5] == "2"
     kw = {}
     if two_species:
@@ -29,9 +31,9 @@ def main():
         dev = None
     else:
         from mcs_amd import hip_backend
-        local = int(os.environ.get("LOCAL_RANK", rank))
+        local = 0 if backend_kind == "hip-gloo" else int(os.environ.get("LOCAL_RANK", rank))
         torch.cuda.set_device(local)
-        be = hip_backend.HipBackend(local)
+        be = hip_backend.HipBackend(local, torch_tallies=True)
         dev = torch.device("cuda", local)
     be.create(prob)
     comm = mcs.driver.Comm(True, dev)

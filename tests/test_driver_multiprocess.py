@@ -24,9 +24,14 @@ def _launch(world, out, N, npc, extra=()):
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), out, "oracle", str(N), str(npc), *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        o, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, o.decode()[-3000:]
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            assert p.returncode == 0, o.decode()[-3000:]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
 
 
 def _single(N, npc, two=False):

@@ -173,6 +173,42 @@ def test_results_do_not_depend_on_launch_geometry():
     assert_tallies_close(mcs.capi.Layout(prob.params), outs[0][1][0], outs[1][1][0], TALLY_RTOL)
 
 
+def test_two_ranks_device_side_merge():
+    """Two ranks of the host driver sharing this GPU (CUDA tensors over gloo): the device-side
+    tally merge (bound torch tensors, in-place all-reduce, rank-0-only baselines) must
+    reproduce the single-process HIP run."""
+    import os, socket, subprocess, sys, tempfile
+    from conftest import ROOT
+    N, npc = 3000, 9
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = os.path.join(tempfile.mkdtemp(), "w2.npz")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), out, "hip-gloo", str(N), str(npc), "2"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=150)
+            assert p.returncode == 0, o.decode()[-3000:]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2,
+                            species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)],
+                            energy_transfer_frac=0.1)
+    prob = mcs.inputs.build_problem(cfg)
+    hb = hip_backend(prob)
+    ref = mcs.driver.run(prob, hb, None, n_itrs=2, max_pcuts=npc)
+    got = np.load(out)
+    stats_ref = np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in ref.stats])
+    assert np.array_equal(got["stats"], stats_ref)
+    assert np.array_equal(got["i"], ref.tallies_i64)
+    assert_tallies_close(mcs.capi.Layout(prob.params), got["f"], ref.tallies_f64, 1e-10)
+    hb.destroy()
+
+
 def test_full_size_properties_1e6():
     """BASELINE config[1] size (10^6 protons): size-independent properties.  (i) every
     particle leaves through exactly one exit and weight is conserved through splitting;
