@@ -231,6 +231,32 @@ int mcs_run_pcut_host(mcs_ctx* ctx, int i_pcut, int64_t n_pts_use, int64_t i_prt
 int mcs_read_tallies(mcs_ctx* ctx, double* host_f64 /*layout.total*/, int64_t* host_i64 /*mcs_i64_total*/);
 int mcs_write_tallies(mcs_ctx* ctx, const double* host_f64, const int64_t* host_i64);
 
+/* ---- consumers of the tallies, on the device-resident histograms ----
+ * Host-made tables (O(bins), O(n_grid)); the edges are cgs momenta and true cos(theta) in the
+ * intended order (consumer quirks C1, C2 in DESIGN.md). */
+typedef struct mcs_consumer_in {
+  const double* mom_log_cgs;    /* [nmom+2] log10 of the momentum bin edges (cgs)               */
+  const double* mom_edge_cgs;   /* [nmom+2] the edges themselves                                */
+  const double* cos_edge;       /* [ntht+2] true cos(theta) of the angle bin edges              */
+  const double* cos_center;     /* [ntht+1] thermo_calcs.jl:57-73                               */
+  const double* pt_center;      /* [nmom+1] thermo_calcs.jl:75-80 (cgs)                         */
+  const double* zone_pop;       /* [n_grid] set_grid_volumes! (particle_counter.jl:1466-1524)   */
+  const double* density_loc;    /* [n_grid] gam0 beta0 n0 / sqrt(gam_sf^2 - 1) (thermo_calcs.jl:258) */
+  const double* cold_pressure;  /* [n_grid] density_loc^(5/3) kB T0 (thermo_calcs.jl:266)       */
+  double rest_energy;           /* m c^2 of the species                                         */
+  double mc;                    /* m c                                                          */
+  double n0;                    /* far-upstream density of the species                          */
+  double gam0;
+  int therm_from_hist;          /* 1: thermal crossings from the therm_pf histogram (A9, C5)    */
+} mcs_consumer_in;
+/* get_dNdp_cr + the CR normalisation of get_normalized_dNdp (src/particle_counter.jl:29-306,
+ * 733-790) on the resident psd.  dNdp: host [3][n_grid][nmom+2] (frame: shock, plasma, ISM).
+ * diag: host [2] (cells skipped on identify_corners error paths; searches that left the table). */
+int mcs_dndp_cr(mcs_ctx* ctx, const mcs_consumer_in* in, double* dNdp, int64_t* diag);
+/* thermo_calcs (src/thermo_calcs.jl:30-352) on the resident psd / therm_pf / num_crossings.
+ * Outputs: host [n_grid] each. */
+int mcs_thermo_calcs(mcs_ctx* ctx, const mcs_consumer_in* in, double* P_par, double* P_perp, double* energy_density);
+
 /* ---- test / measurement hooks ------------------------------------------- */
 /* evaluate device math/RNG primitives (bit-parity tests): fn ids in mcs_fn */
 enum mcs_fn { MCS_FN_SIN = 0, MCS_FN_COS, MCS_FN_ASIN, MCS_FN_ACOS, MCS_FN_ATAN2, MCS_FN_LOG10,

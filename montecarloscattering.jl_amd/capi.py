@@ -57,6 +57,17 @@ class McsSoa(ct.Structure):
     ]
 
 
+class McsConsumerIn(ct.Structure):
+    """`mcs_consumer_in`: host tables for the tally consumers (include/mcs.h)."""
+    _fields_ = [
+        ("mom_log_cgs", c_double_p), ("mom_edge_cgs", c_double_p), ("cos_edge", c_double_p),
+        ("cos_center", c_double_p), ("pt_center", c_double_p), ("zone_pop", c_double_p),
+        ("density_loc", c_double_p), ("cold_pressure", c_double_p),
+        ("rest_energy", ct.c_double), ("mc", ct.c_double), ("n0", ct.c_double), ("gam0", ct.c_double),
+        ("therm_from_hist", ct.c_int),
+    ]
+
+
 F64_FIELDS = ("weight", "ptot_pf", "pb_pf", "x_PT_cm", "xn_per", "prp_x_cm", "acctime_sec", "phi_rad")
 I64_FIELDS = ("grid", "tcut")
 U8_FIELDS = ("downstream", "inj")
@@ -213,6 +224,8 @@ def load_library() -> ct.CDLL:
         "mcs_last_kernel_ms": (dbl, [vp]),
         "mcs_set_launch": (i32, [vp, i32, i32]),
         "mcs_get_layout": (i32, [ct.POINTER(McsParams), c_int64_p]),
+        "mcs_dndp_cr": (i32, [vp, ct.POINTER(McsConsumerIn), c_double_p, c_int64_p]),
+        "mcs_thermo_calcs": (i32, [vp, ct.POINTER(McsConsumerIn), c_double_p, c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing: fail loudly
@@ -228,5 +241,5 @@ EXPORTED_SYMBOLS = [
     "mcs_begin_species", "mcs_set_fluxes", "mcs_pop_upload", "mcs_pop_download", "mcs_saved_download",
     "mcs_pop_size", "mcs_init_pop", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
-    "mcs_get_layout",
+    "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
 ]

@@ -1,0 +1,161 @@
+"""Host side of the tally consumers: the part of `ion_finalize`
+(src/ion_finalize.jl:26-48) that turns the PSD into spectra and pressures.
+
+The reductions over the 22 MB histograms run on the device (`mcs_dndp_cr`, `mcs_thermo_calcs`
+in include/mcs.h); this module only builds the O(bins) / O(n_grid) tables they take and
+mirrors the reference's call order.  Consumer quirks C1-C6 are listed in DESIGN.md section 3b.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import dataclasses
+import math
+
+import numpy as np
+
+from . import capi
+from .constants import C, KB, MP
+
+PC_CM = 3.0856775814913674e18      # UnitfulAstro.pc in cm
+
+
+def angle_edges_intended(prob) -> np.ndarray:
+    """theta (rad) for the log region then cosines for the linear region, in the order
+    `set_psd_angle_bins` builds them before its `sort!` (src/initializers.jl:272-279; quirk C2)."""
+    P, cfg = prob.params, prob.cfg
+    bpd = P.psd_bins_per_dec_tht
+    lin = cfg.psd_linear_cosine_bins
+    log_bins = P.num_psd_tht_bins - lin                # entries 1..log_bins hold theta
+    b = [1.0e-99] + [P.psd_tht_min * (10.0 ** (1 / bpd)) ** k for k in range(log_bins)]
+    b += [P.psd_cos_fine - P.psd_dcos * k for k in range(lin + 1)]
+    b = np.asarray(b)
+    assert len(b) == P.num_psd_tht_bins + 2, (len(b), P.num_psd_tht_bins)
+    return b
+
+
+def find_shock_index(x_grid: np.ndarray) -> int:
+    """src/particle_counter.jl:936-947 (x_grid indexed 0..n_grid+1)."""
+    for i in range(len(x_grid) - 1):
+        if x_grid[i] == 0 or x_grid[i] * x_grid[i + 1] < 0:
+            return i
+    return 0
+
+
+def set_grid_volumes(prob, i_ion: int):
+    """`set_grid_volumes!` (src/particle_counter.jl:1466-1524) -> (zone_pop, zone_vol), zones 1..n_grid."""
+    P, cfg = prob.params, prob.cfg
+    x, ux, gsf = prob.x_grid_cm, prob.ux, prob.gam_sf
+    n = P.n_grid
+    i_shock = find_shock_index(x)
+    dx = np.diff(x)                                  # dx[i] = x[i+1]-x[i], i = 0..n_grid
+    sph = jet_sphere_fraction(cfg)
+    jet_rad_cm = cfg.jet_shock_radius * PC_CM
+    surf = np.zeros(n + 1)
+    rad_min = jet_rad_cm - x[i_shock]
+    for i in range(i_shock - 1, 0, -1):
+        rad_max = rad_min + dx[i] / P.gam0
+        surf[i] = math.pi * (rad_max + rad_min) ** 2 * sph
+        rad_min = rad_max
+    rad_max = jet_rad_cm - x[i_shock]
+    for i in range(i_shock, n + 1):
+        rad_min = rad_max - dx[i] / P.gam0
+        surf[i] = math.pi * (rad_max + rad_min) ** 2 * sph
+        rad_max = rad_min
+    n0 = cfg.species[i_ion - 1].density
+    zone_pop = np.zeros(n)
+    zone_vol = np.zeros(n)
+    for i in range(1, n + 1):
+        dwell = dx[i] / ux[i]
+        F_up = P.gam0 * n0 * P.beta0 * C
+        zone_pop[i - 1] = F_up * surf[i] * dwell
+        density_pf = P.gam0 * ux[1] / (gsf[i] * ux[i])
+        zone_vol[i - 1] = zone_pop[i - 1] / density_pf
+    return zone_pop, zone_vol
+
+
+def jet_sphere_fraction(cfg) -> float:
+    """`parse_jet_frac` (src/data_input.jl:153-167)."""
+    if cfg.JETFR is None:
+        return 0.0
+    frac, ang = cfg.JETFR
+    if 0 < frac <= 1:
+        return float(frac)
+    if 0 < ang <= 180:
+        return (1 - math.cos(math.radians(ang))) / 2
+    raise ValueError("JETFR: Unphysical values entered.")
+
+
+@dataclasses.dataclass
+class ConsumerTables:
+    mom_log_cgs: np.ndarray
+    mom_edge_cgs: np.ndarray
+    cos_edge: np.ndarray
+    cos_center: np.ndarray
+    pt_center: np.ndarray
+    zone_pop: np.ndarray
+    zone_vol: np.ndarray
+    density_loc: np.ndarray
+    cold_pressure: np.ndarray
+    rest_energy: float
+    mc: float
+    n0: float
+    gam0: float
+    therm_from_hist: int = 1
+
+    def as_struct(self) -> capi.McsConsumerIn:
+        s = capi.McsConsumerIn()
+        for f in ("mom_log_cgs", "mom_edge_cgs", "cos_edge", "cos_center", "pt_center", "zone_pop", "density_loc",
+                  "cold_pressure"):
+            a = getattr(self, f)
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+            setattr(s, f, a.ctypes.data_as(capi.c_double_p))
+        s.rest_energy, s.mc, s.n0, s.gam0 = self.rest_energy, self.mc, self.n0, self.gam0
+        s.therm_from_hist = int(self.therm_from_hist)
+        return s
+
+
+def consumer_tables(prob, i_ion: int, therm_from_hist: bool = True) -> ConsumerTables:
+    """Tables of get_dNdp_cr (src/particle_counter.jl:46-62), transform_psd_corners
+    (src/transformers.jl:646-660) and thermo_calcs (src/thermo_calcs.jl:55-80, 246, 258-266)."""
+    P, cfg = prob.params, prob.cfg
+    sp = cfg.species[i_ion - 1]
+    nm, nt = P.num_psd_mom_bins, P.num_psd_tht_bins
+    lin = cfg.psd_linear_cosine_bins
+    mb = np.asarray(prob.psd_mom_bounds, dtype=np.float64)           # log10(p / m_p c), index 0..nm+1
+    mom_edge = np.ascontiguousarray(10.0 ** mb * (MP * C))           # C1: cgs
+    mom_log = np.ascontiguousarray(np.log10(mom_edge))
+    tb = angle_edges_intended(prob)                                  # C2
+    j = np.arange(nt + 2)
+    cos_edge = np.ascontiguousarray(np.where(j > nt - lin, -tb, -np.cos(tb)))
+    cos_center = np.ascontiguousarray(0.5 * (cos_edge[:-1] + cos_edge[1:]))            # thermo_calcs.jl:57-73
+    pt_center = np.ascontiguousarray(10.0 ** (0.5 * (mb[:-1] + mb[1:])) * (MP * C))    # thermo_calcs.jl:75-80
+    zone_pop, zone_vol = set_grid_volumes(prob, i_ion)
+    x, ux, gsf = prob.x_grid_cm, prob.ux, prob.gam_sf
+    n = P.n_grid
+    with np.errstate(divide="ignore", invalid="ignore"):
+        density_loc = P.gam0 * P.beta0 * sp.density / np.sqrt(gsf[1:n + 1] ** 2 - 1)
+    cold_pressure = density_loc ** (5.0 / 3.0) * KB * sp.temperature
+    m = sp.aa * MP
+    return ConsumerTables(mom_log, mom_edge, cos_edge, cos_center, pt_center,
+                          np.ascontiguousarray(zone_pop), np.ascontiguousarray(zone_vol),
+                          np.ascontiguousarray(density_loc), np.ascontiguousarray(cold_pressure),
+                          m * C * C, m * C, sp.density, P.gam0, int(therm_from_hist))
+
+
+@dataclasses.dataclass
+class IonFinal:
+    """What `ion_finalize` returns for the transport consumers (src/ion_finalize.jl:78-82)."""
+    dNdp_cr: np.ndarray          # [3][n_grid][nmom+2]: shock, plasma, ISM frame; normalised dN/dp
+    zone_pop: np.ndarray
+    P_psd_par: np.ndarray
+    P_psd_perp: np.ndarray
+    energy_density_psd: np.ndarray
+    diag: np.ndarray
+
+
+def ion_finalize(prob, backend, i_ion: int, therm_from_hist: bool = True) -> IonFinal:
+    """get_normalized_dNdp (CR part) then thermo_calcs, on the backend's resident tallies."""
+    tabs = consumer_tables(prob, i_ion, therm_from_hist)
+    dndp, diag = backend.dndp_cr(tabs)
+    ppar, pperp, edens = backend.thermo_calcs(tabs)
+    return IonFinal(dndp, tabs.zone_pop, ppar, pperp, edens, diag)

@@ -28,6 +28,11 @@ hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* 
 hipError_t mcs_launch_fill(double* p, long long n, double v, hipStream_t st);
 hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStream_t st);
 hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b, double* out, hipStream_t st);
+hipError_t mcs_launch_dndp_cr(const mcs_params* P, const double* psd, const double* gam_sf, const double* ux, const double* tabs,
+                              double rest_energy, double n0, double gam0, double* out_dndp, unsigned long long* diag, hipStream_t st);
+hipError_t mcs_launch_thermo(const mcs_params* P, const double* psd, const double* therm_pf, const unsigned long long* num_crossings,
+                             const double* gam_sf, const double* ux, const double* tabs, double rest_energy, double mc, double n0,
+                             int therm_from_hist, double* scratch, double* out3, hipStream_t st);
 }
 
 namespace {
@@ -78,6 +83,8 @@ struct mcs_ctx {
   int i_iter = 1, i_ion = 1;
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
   bool have_grid = false, have_cuts = false;
+  // consumers (K4): table staging, outputs, thermo scratch slab
+  double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
   // launch
   int blocks = 0, threads = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -239,7 +246,8 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args};
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args,
+                  c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
@@ -540,5 +548,65 @@ int mcs_final_download(mcs_ctx* c, int64_t n, int32_t* reason, int32_t* helix_co
 }
 
 double mcs_last_kernel_ms(mcs_ctx* c) { return c->last_ms; }
+
+// ---- consumers of the tallies (K4) ------------------------------------------------------
+static int consumers_ready(mcs_ctx* c, const mcs_consumer_in* in, const char* who) {
+  if (!c || !in) return fail(std::string(who) + ": null argument");
+  if (!c->have_grid) return fail(std::string(who) + ": grid not set");
+  if (c->P.num_psd_mom_bins + 2 > 208 || c->P.num_psd_tht_bins + 2 > 208) return fail(std::string(who) + ": too many PSD bins");
+  const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
+  if (!c->d_ctab) HIPCHK(hipMalloc((void**)&c->d_ctab, sizeof(double) * (size_t)(3 * NM + 2 * NT + 4 * ng)));
+  if (!c->d_cout) HIPCHK(hipMalloc((void**)&c->d_cout, sizeof(double) * (size_t)(3 * ng * NM + 3 * ng)));
+  if (!c->d_cdiag) HIPCHK(hipMalloc((void**)&c->d_cdiag, sizeof(unsigned long long) * 2));
+  return 0;
+}
+
+int mcs_dndp_cr(mcs_ctx* c, const mcs_consumer_in* in, double* dNdp, int64_t* diag) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (consumers_ready(c, in, "mcs_dndp_cr")) return 1;
+  if (!in->mom_log_cgs || !in->mom_edge_cgs || !in->cos_edge || !in->zone_pop || !dNdp) return fail("mcs_dndp_cr: null table");
+  const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
+  std::vector<double> h((size_t)(2 * NM + NT + ng));
+  memcpy(h.data(), in->mom_log_cgs, sizeof(double) * NM);
+  memcpy(h.data() + NM, in->mom_edge_cgs, sizeof(double) * NM);
+  memcpy(h.data() + 2 * NM, in->cos_edge, sizeof(double) * NT);
+  memcpy(h.data() + 2 * NM + NT, in->zone_pop, sizeof(double) * ng);
+  HIPCHK(hipMemcpyAsync(c->d_ctab, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_cdiag, 0, sizeof(unsigned long long) * 2, c->stream));
+  HIPCHK(mcs_launch_dndp_cr(&c->P, c->d_T + c->L.psd, c->tb.gsf, c->tb.ux, c->d_ctab, in->rest_energy, in->n0, in->gam0,
+                            c->d_cout, c->d_cdiag, c->stream));
+  HIPCHK(hipMemcpyAsync(dNdp, c->d_cout, sizeof(double) * (size_t)(3 * ng * NM), hipMemcpyDeviceToHost, c->stream));
+  unsigned long long hd[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(hd, c->d_cdiag, sizeof(hd), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (diag) { diag[0] = (int64_t)hd[0]; diag[1] = (int64_t)hd[1]; }
+  return 0;
+}
+
+int mcs_thermo_calcs(mcs_ctx* c, const mcs_consumer_in* in, double* P_par, double* P_perp, double* energy_density) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (consumers_ready(c, in, "mcs_thermo_calcs")) return 1;
+  if (!in->cos_center || !in->pt_center || !in->zone_pop || !in->density_loc || !in->cold_pressure || !P_par || !P_perp || !energy_density)
+    return fail("mcs_thermo_calcs: null table");
+  const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
+  if (!c->d_cscratch) HIPCHK(hipMalloc((void**)&c->d_cscratch, sizeof(double) * (size_t)NM * NT * ng));
+  std::vector<double> h((size_t)(NT + NM + 3 * ng), 0.0);
+  memcpy(h.data(), in->cos_center, sizeof(double) * (NT - 1));
+  memcpy(h.data() + NT, in->pt_center, sizeof(double) * (NM - 1));
+  memcpy(h.data() + NT + NM, in->zone_pop, sizeof(double) * ng);
+  memcpy(h.data() + NT + NM + ng, in->density_loc, sizeof(double) * ng);
+  memcpy(h.data() + NT + NM + 2 * ng, in->cold_pressure, sizeof(double) * ng);
+  HIPCHK(hipMemcpyAsync(c->d_ctab, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  double* out3 = c->d_cout + (size_t)3 * ng * NM;
+  HIPCHK(mcs_launch_thermo(&c->P, c->d_T + c->L.psd, c->d_T + c->L.therm_pf, c->d_I + MCS_I_NUM_CROSSINGS, c->tb.gsf, c->tb.ux,
+                           c->d_ctab, in->rest_energy, in->mc, in->n0, in->therm_from_hist, c->d_cscratch, out3, c->stream));
+  std::vector<double> o((size_t)3 * ng);
+  HIPCHK(hipMemcpyAsync(o.data(), out3, sizeof(double) * o.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(P_par, o.data(), sizeof(double) * ng);
+  memcpy(P_perp, o.data() + ng, sizeof(double) * ng);
+  memcpy(energy_density, o.data() + 2 * ng, sizeof(double) * ng);
+  return 0;
+}
 
 }  // extern "C"

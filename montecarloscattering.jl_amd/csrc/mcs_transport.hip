@@ -198,6 +198,20 @@ __device__ __forceinline__ void ladd_i32(int* p, int v) {
 // per-particle global atomic on ONE address serialises at ~12 ns each (1e6 particles = 12 ms).
 __shared__ unsigned int g_ctr[MCS_IC_COUNT + 1];
 __shared__ double g_sc[8];   // [0..3] layout.scalars, [4] esc_flux, [5] px_esc_feb, [6] energy_esc_feb (this ion/iter)
+
+// ---- optional phase profile (-DMCS_PROF; tools/gpu_prof.py): cycle / lane counts per loop phase
+#ifdef MCS_PROF
+#define MCS_NPROF 32
+__device__ unsigned long long g_prof[MCS_NPROF];
+__shared__ unsigned long long S_prof[MCS_NPROF];
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, v) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)(v)); } while (0)
+#define PROF_LANES(slot, pred) do { const unsigned long long m__ = __ballot(pred); if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)__popcll(m__)); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(slot, v) do { } while (0)
+#define PROF_LANES(slot, pred) do { } while (0)
+#endif
 __device__ __forceinline__ void cnt(CK* a, int which, unsigned int v = 1u) {
   (void)a;
   (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int*)&g_ctr[which], v, __ATOMIC_RELAXED,
@@ -721,11 +735,14 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
 
   // ================= phase A =================
   const bool block1 = p.i_return == 1;
+  [[maybe_unused]] const unsigned long long pa0 = PROF_T();
   {
     const bool capped = p.helix > MCS_HELIX_CAP;
     const bool zone_ev = !block1 && (p.i_grid != p.ig3 || h.custom_epsB);
     const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
+    PROF_LANES(13, capped | block1 | zone_ev | etf_ev);
     if (capped | block1 | zone_ev | etf_ev) {
+      PROF_ADD(12, 1);
       if (capped) {
         cnt(a, MCS_IC_HELIX_CAP);
         end = 1;                                                      // quirk Q5
@@ -758,6 +775,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
     }
   }
 
+  PROF_ADD(14, PROF_T() - pa0);
   bool ev_tcut = false;
   if (end < 0 && !block1) {
     // ================= phase B, Code Block 3 (particle_loop.jl:251-385) =================
@@ -845,7 +863,12 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
   p.i_return = 2;                                             // prob_return's default (prob_return.jl:48)
 
   // ================= phase C =================
+  [[maybe_unused]] const unsigned long long pc0 = PROF_T();
+  PROF_ADD(26, pc0 - pa0);    // phases A+B (lanes that reach the move)
+  PROF_LANES(16, ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp);
+  PROF_LANES(22, ev_flux); PROF_LANES(23, ev_dtest); PROF_LANES(24, ev_prp); PROF_LANES(25, ev_tcut);
   if (ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp) {
+    PROF_ADD(15, 1);
     if (ev_tcut) {
       tcut_track(a, p.tcut, p.weight, p.ptot_pf);
       p.tcut += 1;
@@ -898,6 +921,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
         S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
         if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
         p.pushed = true;
+        PROF_ADD(19, 1); PROF_LANES(18, true);
       }
     }
     // downstream_test (particle_loop.jl:595-637) and prob_return; after a reflection or a
@@ -928,6 +952,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
       return lose_pt ? 4 : 1;
     }
   }
+  PROF_ADD(17, PROF_T() - pc0);
   return -1;
 }
 
@@ -972,6 +997,9 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
   if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
   if (threadIdx.x < 4) S_evcur[threadIdx.x] = 0u;
+#ifdef MCS_PROF
+  if (threadIdx.x < MCS_NPROF) S_prof[threadIdx.x] = 0ull;
+#endif
   __syncthreads();
 
   // Hot-loop constants are parked in VGPRs behind an opaque move: the compiler can then
@@ -1012,9 +1040,12 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.pushed = false;
   for (;;) {
+    [[maybe_unused]] const unsigned long long pt0 = PROF_T();
     ev_pending += (unsigned)__popcll(__ballot(p.pushed));
     p.pushed = false;
-    if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; }
+    if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
+    [[maybe_unused]] const unsigned long long pt1 = PROF_T();
+    PROF_ADD(2, pt1 - pt0);
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
     if (idle != 0ull && !exhausted) {
@@ -1034,14 +1065,27 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
           active = true;
         }
       }
+      PROF_ADD(5, 1); PROF_ADD(6, nidle);
+    }
+    [[maybe_unused]] const unsigned long long pt2 = PROF_T();
+    PROF_ADD(4, pt2 - pt1);
+    {
+      const int na__ = __popcll(__ballot(active));
+      PROF_ADD(0, 1); PROF_ADD(8, na__);
+      if (na__ <= 8) PROF_ADD(21, 1);
     }
     if (__ballot(active) == 0ull) {
       if (exhausted) break;
       continue;
     }
+    int end = -1;
+    if (active) end = helix_step(a, s, h, kc, rng, p);
+    [[maybe_unused]] const unsigned long long pt3 = PROF_T();
+    PROF_ADD(7, pt3 - pt2);
+    PROF_LANES(11, active && end >= 0);
     if (active) {
-      const int end = helix_step(a, s, h, kc, rng, p);
       if (end >= 0) {
+        PROF_ADD(10, 1);
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
         if (end == 0) {
@@ -1062,6 +1106,10 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
         active = false;
       }
     }
+    [[maybe_unused]] const unsigned long long pt4 = PROF_T();
+    PROF_ADD(9, pt4 - pt3);
+    PROF_ADD(1, pt4 - pt0);
+    PROF_ADD(20, PROF_T() - pt4);   // cost of one timer read
   }
 
   // ---- flush per-lane counters (wave reduce) and the LDS staging
@@ -1077,6 +1125,9 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     if (c_draws) gadd_u64(&a->I[ng + MCS_IC_RNG_DRAWS], c_draws);
   }
   __syncthreads();
+#ifdef MCS_PROF
+  if (threadIdx.x < MCS_NPROF && S_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], S_prof[threadIdx.x]);
+#endif
   if (threadIdx.x < MCS_IC_COUNT) {
     const unsigned int c = g_ctr[threadIdx.x];
     if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
@@ -1103,6 +1154,13 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   }
 }
 
+#ifdef MCS_PROF
+extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * MCS_NPROF) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[MCS_NPROF] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_grid; (void)n_tcuts; return 0; }   // static LDS
 extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 

@@ -160,6 +160,24 @@ class HipBackend:
         i = np.ascontiguousarray(i, dtype=np.int64)
         self._chk(self.lib.mcs_write_tallies(self.h, _dp(f), i.ctypes.data_as(c_int64_p)))
 
+    # -- consumers of the tallies (K4)
+    def dndp_cr(self, tabs):
+        """get_dNdp_cr + CR normalisation on the resident psd -> ([3][n_grid][nmom+2], diag[2])."""
+        P = self.P
+        out = np.zeros((3, P.n_grid, P.num_psd_mom_bins + 2))
+        diag = np.zeros(2, dtype=np.int64)
+        s = tabs.as_struct()
+        self._chk(self.lib.mcs_dndp_cr(self.h, ct.byref(s), _dp(out), diag.ctypes.data_as(c_int64_p)))
+        return out, diag
+
+    def thermo_calcs(self, tabs):
+        """thermo_calcs on the resident psd / therm_pf / num_crossings -> (P_par, P_perp, energy_density)."""
+        n = self.P.n_grid
+        a, b, c = np.zeros(n), np.zeros(n), np.zeros(n)
+        s = tabs.as_struct()
+        self._chk(self.lib.mcs_thermo_calcs(self.h, ct.byref(s), _dp(a), _dp(b), _dp(c)))
+        return a, b, c
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.mcs_last_kernel_ms(self.h))
 

@@ -104,6 +104,8 @@ class Config:
     use_custom_frg: bool = False
     EMNFC: float = 0.01
     INJFR: Optional[Sequence[float]] = None
+    jet_shock_radius: float = 0.438     # pc   (mc_in.toml:192)
+    JETFR: Sequence[float] = (0.0, 5.0)  # (sphere fraction, opening angle [deg]); first non-zero used
     # build-specific switches
     grid_variant: str = "intended"      # "intended" | "verbatim" (reference quirk G1)
     track_thermal: bool = True
@@ -128,6 +130,7 @@ _TOML_KEYS = {
     "use-custom-epsB": "use_custom_epsB", "num-psd-bins-per-decade": "num_psd_bins_per_decade",
     "psd-linear-cosine-bins": "psd_linear_cosine_bins", "psd-log-theta-decs": "psd_log_theta_decs",
     "use-custom-frg": "use_custom_frg", "EMNFC": "EMNFC", "INJFR": "INJFR",
+    "jet-shock-radius": "jet_shock_radius", "JETFR": "JETFR",
 }
 
 

@@ -61,6 +61,10 @@ def load(math: str = "det", capi=None):
         "orc_bin_momentum": (i32, [vp, dbl]),
         "orc_bin_angle": (i32, [vp, dbl, dbl]),
     }
+    if capi is not None:
+        cin_p = ct.POINTER(capi.McsConsumerIn)
+        sig["orc_dndp_cr"] = (i32, [par_p, dp, cin_p, dp, dp, dp, i64p])
+        sig["orc_thermo_calcs"] = (i32, [par_p, dp, i64p, cin_p, dp, dp, dp, dp, dp])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -185,6 +189,28 @@ class OracleBackend:
         f = np.ascontiguousarray(f, dtype=np.float64)
         i = np.ascontiguousarray(i, dtype=np.int64)
         self._chk(self.lib.orc_write_tallies(self.h, _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64))))
+
+    # -- consumers of the tallies (oracle/mcs_consumers.cpp)
+    def dndp_cr(self, tabs, tallies=None):
+        f, _ = self.read_tallies() if tallies is None else tallies
+        ux, gsf = np.ascontiguousarray(self.prob.ux), np.ascontiguousarray(self.prob.gam_sf)
+        P = self.P
+        out = np.zeros((3, P.n_grid, P.num_psd_mom_bins + 2))
+        diag = np.zeros(2, dtype=np.int64)
+        s = tabs.as_struct()
+        self._chk(self.lib.orc_dndp_cr(ct.byref(P), _dp(f), ct.byref(s), _dp(gsf), _dp(ux), _dp(out),
+                                       diag.ctypes.data_as(ct.POINTER(ct.c_int64))))
+        return out, diag
+
+    def thermo_calcs(self, tabs, tallies=None):
+        f, i = self.read_tallies() if tallies is None else tallies
+        ux, gsf = np.ascontiguousarray(self.prob.ux), np.ascontiguousarray(self.prob.gam_sf)
+        n = self.P.n_grid
+        a, b, c = np.zeros(n), np.zeros(n), np.zeros(n)
+        s = tabs.as_struct()
+        self._chk(self.lib.orc_thermo_calcs(ct.byref(self.P), _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64)), ct.byref(s),
+                                            _dp(gsf), _dp(ux), _dp(a), _dp(b), _dp(c)))
+        return a, b, c
 
     def last_kernel_ms(self):
         return float("nan")

@@ -126,8 +126,28 @@ def run_case(backend, prob, spec, record):
     return out
 
 
+def make_consumers(N=600):
+    """consumers_n600.npz: dN/dp (3 frames, normalised) and thermo_calcs outputs of the oracle
+    (oracle/mcs_consumers.cpp) on the tallies of a full single-threaded N=600 iteration."""
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
+    prob = mcs.inputs.build_problem(cfg)
+    be = orc.OracleBackend(mcs.capi, "det", nthreads=1)
+    be.create(prob)
+    res = mcs.driver.run(prob, be, n_itrs=1)
+    be.write_tallies(res.tallies_f64, res.tallies_i64)
+    fin = mcs.consumers.ion_finalize(prob, be, 1)
+    idx = np.nonzero(fin.dNdp_cr > 1e-90)
+    path = os.path.join(HERE, f"consumers_n{N}.npz")
+    np.savez_compressed(path, dndp_idx=np.asarray(idx, dtype=np.int32), dndp_val=fin.dNdp_cr[idx], diag=fin.diag,
+                        P_par=fin.P_psd_par, P_perp=fin.P_psd_perp, e_dens=fin.energy_density_psd, zone_pop=fin.zone_pop)
+    print(f"consumers_n{N}: {len(idx[0])} non-empty dN/dp entries, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     orc.build()
+    make_consumers()
+    if "--consumers-only" in sys.argv:
+        return
     for name in CASES:
         prob, spec = build_case(name)
         be = orc.OracleBackend(mcs.capi, "det", nthreads=1)

@@ -1,0 +1,45 @@
+"""Phase profile of K1 (needs csrc/libmcs_hip_prof.so, built with -DMCS_PROF; run with
+MCS_HIP_LIB=libmcs_hip_prof.so): per pcut, wave-cycles and lane counts per loop phase.
+usage: MCS_HIP_LIB=libmcs_hip_prof.so python tools/gpu_prof.py N NPC [first_pcut_to_print]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import ctypes as ct
+import _mcs_loader; m = _mcs_loader.load()
+from mcs_amd import hip_backend
+N = int(sys.argv[1]); NPC = int(sys.argv[2]); FIRST = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
+prob = m.inputs.build_problem(cfg)
+hb = hip_backend.HipBackend(0); hb.create(prob)
+hb.begin_iteration(1)
+inj = m.inputs.init_pop_host(prob, 1)
+hb.begin_species(1, 1, 1.0, 1.0, prob.pmax, 1.0, 1.0)
+hb.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+hb.init_pop(inj, 0, inj.n_pts_use, inj.n_pts_use)
+ng = prob.n_grid; IC = m.capi.IC
+prof = np.zeros(32, dtype=np.uint64)
+hb.lib.mcs_prof_read.argtypes = [ct.c_void_p, ct.c_int]
+prev = 0
+for ip in range(1, NPC + 1):
+    n = hb.pop_size()
+    ns = hb.run_pcut(ip, 0)
+    i64 = np.zeros(hb.layout.n_i64, dtype=np.int64)
+    hb.lib.mcs_read_tallies(hb.h, None, i64.ctypes.data_as(ct.POINTER(ct.c_int64)))
+    st = int(i64[ng + IC["STEPS_HELIX"]] + i64[ng + IC["STEPS_RETRO"]]); d = st - prev; prev = st
+    ms = hb.last_kernel_ms()
+    assert hb.lib.mcs_prof_read(prof.ctypes.data, 1) == 0
+    P = prof.astype(np.float64)
+    if ip >= FIRST:
+        passes = P[0]; tr = P[20] / max(passes, 1)          # cycles of one timer read
+        def cyc(slot, reads=1): return P[slot] - reads * tr * passes
+        tot = cyc(1)
+        print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3):.3e}/s  (timer read = {tr:.0f} cyc)")
+        print(f"   wave passes {passes:.3e}, active lanes/pass {P[8]/passes:.1f}, passes with <=8 active {100*P[21]/passes:.1f} %, cycles/pass {tot/passes:.0f}")
+        print(f"   share of wave-cycles: drain {100*cyc(2)/tot:.1f} %  refill {100*cyc(4)/tot:.1f} %  step {100*cyc(7)/tot:.1f} %  finish {100*cyc(9)/tot:.1f} %")
+        print(f"   inside step: A {100*(P[14]-tr*passes)/tot:.1f} %   A+B(to move) {100*(P[26]-tr*passes)/tot:.1f} %   C {100*(P[17]-tr*passes)/tot:.1f} %")
+        print(f"   drains/pass {P[3]/passes:.4f}  refills/pass {P[5]/passes:.4f} ({P[6]/max(P[5],1):.1f} lanes each)  finish passes/pass {P[10]/passes:.4f} ({P[11]/max(P[10],1):.1f} lanes each)")
+        print(f"   phase A entered {100*P[12]/passes:.1f} % of passes ({P[13]/max(P[12],1):.1f} lanes each);  phase C entered {100*P[15]/passes:.1f} % ({P[16]/max(P[15],1):.1f} lanes each)")
+        print(f"   C causes per pass (lanes): flux {P[22]/passes:.2f} dtest {P[23]/passes:.2f} prp {P[24]/passes:.2f} tcut {P[25]/passes:.2f}; pushes/pass {P[19]/passes:.3f} ({P[18]/max(P[19],1):.1f} lanes each)", flush=True)
+    if ns == 0: break
+    hb.new_pcut(max(N // ns, 1))
