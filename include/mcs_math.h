@@ -33,25 +33,12 @@
 #pragma clang fp contract(off)
 #endif
 
-/* MCS_SC(c): a coefficient at its point of use.  On gfx950 the constant is built in a
- * scalar register pair right where it is consumed (2 s_mov_b32, free on the scalar pipe)
- * instead of being hoisted out of the particle loop into VGPRs: hipcc otherwise keeps
- * ~150 VGPRs of polynomial coefficients live across the whole transport loop.  The value
- * is unchanged, so results are bit-identical with and without it. */
-#if defined(__HIP_DEVICE_COMPILE__)
-namespace mcsm {
-/* two s_mov_b32 with literal operands write the constant into a fresh SGPR pair */
-template <unsigned LO, unsigned HI> __device__ __forceinline__ double sc2_() {
-  unsigned lo, hi;
-  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-}
-#define MCS_SC(c) (::mcsm::sc2_<(unsigned)(__builtin_bit_cast(unsigned long long, (double)(c)) & 0xffffffffull), \
-                                (unsigned)(__builtin_bit_cast(unsigned long long, (double)(c)) >> 32)>())
-#else
+/* MCS_SC(c): a coefficient at its point of use.  Plain literal: the device build passes
+ * `-mllvm -disable-machine-licm`, which is what keeps hipcc from hoisting ~150 VGPRs of
+ * polynomial coefficients out of the particle loop (and then spilling); the constant is
+ * rematerialised where it is consumed.  (Round 1 first used inline-asm s_mov pairs for this;
+ * the compiler had to pad those with s_nop and v_mov, 5-6 instructions per constant.) */
 #define MCS_SC(c) (c)
-#endif
 
 #define MCS_PI      MCS_PI_DD_0
 #define MCS_TWOPI   MCS_TWOPI_DD_0

@@ -90,8 +90,11 @@ __device__ __forceinline__ double fdiv(double a, double b) { return div_r(a, b, 
 // ---- Philox4x32-10 ------------------------------------------------------------
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                              uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+#ifndef MCS_PHILOX_ROUNDS
+#define MCS_PHILOX_ROUNDS 10      /* anything else is a TIMING EXPERIMENT (wrong random numbers) */
+#endif
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < MCS_PHILOX_ROUNDS; ++r) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;   // one v_mad_u64_u32 each
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -129,6 +132,14 @@ struct Rng {
     n = j + 2u;
     uint32_t o0, o1, o2, o3;
     philox_block((j + 1u) >> 1, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
+#ifdef MCS_PHILOX_DOUBLE   /* TIMING EXPERIMENT: a second, dependent block whose result is discarded */
+    {
+      uint32_t q0, q1, q2, q3, z;
+      philox_block(o0, o1, o2, o3, k0, k1, q0, q1, q2, q3);
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      o0 ^= (q0 ^ q1 ^ q2 ^ q3) & z;
+    }
+#endif
     const double a = u64_to_unit(o0, o1), b = u64_to_unit(o2, o3);
     const bool odd = (j & 1u) != 0u;
     u1 = odd ? spare : a;
@@ -162,15 +173,22 @@ struct Lds {                                // kept as an (empty) handle so call
 // The zone properties "of the current pass" (ux, uz, utot, gamma_sf, gamma_ef, sin/cos
 // theta_B; particle_loop.jl:195-204) are the LDS table entries of zone `ig3`, the zone the
 // particle was in when Code Block 3 last ran; they are re-read from LDS where needed.
+#define DIRTY_S 1
+#define DIRTY_M 2
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double dphi;                   // 2pi / xn_per, recomputed only when xn_per changes (particle_loop.jl:529)
   double gyro_denom, gyro_rad, gyro_rad_tot, gyro_period, t_step;
-  double gp_key;                 // gyro_period that t_step was computed from (t_step = gyro_period / xn_per)
-  double rp_key, rp_val;         // refined 1/ptot_pf for the ptot_pf it was computed from
-  double rg_key, rg_val;         // refined 1/(gam_pf*m) for the gam_pf it was computed from
+  // Values that are pure functions of (ptot_pf, gam_pf, gyro_denom, xn_per) and therefore change
+  // only at rare events (frame transform at the shock, energy transfer, radiative loss, PRP return,
+  // field change, fine/coarse switch).  Every such event sets `dirty`; the values are recomputed
+  // -- with the reference's own expressions, so bit-identically -- before their next use:
+  double rp_val;                 // refined 1/ptot_pf                       (DIRTY_S, before the scatter)
+  double cm_val;                 // cos_max of the scattering cone (scattering.jl:60)   (DIRTY_S)
+  double rg_val;                 // refined 1/(gam_pf*m)                    (DIRTY_M, before the move)
   double tcut_next;              // tcuts[tcut-1] (LDS) or +inf
-  double cm_grt, cm_xn, cm_val;  // cache of cos_max for (gyro_rad_tot, xn_per) (scattering.jl:60)
+  int dirty;                     // DIRTY_S | DIRTY_M
+  unsigned n_ovr;                // steps taken past the last time cut (D4 counter, flushed at the end)
   int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
   bool downstream, inj;
   bool pushed;                   // this lane pushed a tally record in the current pass
@@ -312,8 +330,9 @@ __device__ MCS_COLD Mom transform_p_PSP(CK* a, Lds s, int io, int in, double r_p
   return r;
 }
 
-// src/scattering.jl:29-101
-__device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, double mc, double eta, const mcsm::HotCoef& kc) {
+// The slowly varying part of scattering (src/scattering.jl:39-60): gyro period, r_g,tot and the
+// cone cos_max -- functions of (ptot_pf, gam_pf, gyro_denom, xn_per) -- plus the refined 1/ptot_pf.
+__device__ __forceinline__ void refresh_scatter(CK* a, Pt& p, double aa, double mc, double eta) {
   double grt;
   if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
     grt = a->P.pe_crit * CC_ * p.gyro_denom;
@@ -322,16 +341,15 @@ __device__ __forceinline__ void scattering(CK* a, Rng& rng, Pt& p, double aa, do
     grt = p.ptot_pf * CC_ * p.gyro_denom;
     p.gyro_period = TWOPI_ * p.gam_pf * mc * p.gyro_denom;
   }
-  // cos_max is a pure function of (grt, xn_per): recomputed only when either changed
-  if (grt != p.cm_grt || p.xn_per != p.cm_xn) {
-    const double vp_tg = TWOPI_ * grt;
-    const double lam = eta * grt;
-    p.cm_val = mcsm::cos(__builtin_sqrt(6 * vp_tg / (p.xn_per * lam)));
-    p.cm_grt = grt; p.cm_xn = p.xn_per;
-  }
-  const double cos_max = p.cm_val;
+  const double vp_tg = TWOPI_ * grt;
+  const double lam = eta * grt;
+  p.cm_val = mcsm::cos(__builtin_sqrt(6 * vp_tg / (p.xn_per * lam)));
+  p.rp_val = rcp_refined(p.ptot_pf);
+}
 
-  if (p.ptot_pf != p.rp_key) { p.rp_val = rcp_refined(p.ptot_pf); p.rp_key = p.ptot_pf; }
+// src/scattering.jl:61-101: the per-step part (two draws, new pitch, phase adjustment); straight-line code
+__device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef& kc) {
+  const double cos_max = p.cm_val;
   const double cos_old = div_r(p.pb_pf, p.ptot_pf, p.rp_val);      // == pb_pf / ptot_pf
   const double sin_old = div_r(p.p_perp, p.ptot_pf, p.rp_val);     // == p_perp / ptot_pf
   double U1, U2;
@@ -658,6 +676,7 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut_next = r.tcut_next; p.tcut = r.tcut;
       p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
+      p.dirty = DIRTY_S | DIRTY_M;     // radiative losses inside the walk change ptot_pf / gam_pf
       if (lose_pt) p.i_return = 0;
       p.x = p.prp;
     }
@@ -705,144 +724,169 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.gyro_period = TWOPI_ * p.gam_pf * h.m * CC_ * p.gyro_denom;
   p.i_return = -1;
   p.t_step = 0.0;
-  p.gp_key = -1.0;                       // forces the first t_step = gyro_period / xn_per
   p.dphi = TWOPI_ / p.xn_per;
   p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? S_tc[p.tcut - 1] : __builtin_inf();
-  p.cm_grt = -1.0; p.cm_xn = -1.0; p.cm_val = 0.0;
-  p.rp_key = -1.0; p.rp_val = 0.0; p.rg_key = -1.0; p.rg_val = 0.0;
+  p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0;
+  p.dirty = DIRTY_S | DIRTY_M;
+  p.n_ovr = 0u;
   p.pushed = false;
 }
 
 // ------------------------------------------------------------------------------------------
-// One pass of the helix loop (src/particle_loop.jl:154-499), organised for the hardware:
-//   phase A  rare work BEFORE the scatter (helix cap, Code Block 1 after a PRP return, zone
-//            change: field/gyro reload, transform_p_PSP, energy transfer);
-//   phase B  the common step as straight-line code: escape compares, scattering, clock,
-//            pcut test, move, same-zone test (selects, no rare work, no memory waits);
-//   phase C  rare work AFTER the move (time-cut tally, no-DSA reflection, shock crossing,
-//            zone search + flux/PSD tallies, downstream test, PRP logic, retro walk).
-// Each rare item is behind a per-lane flag, so a wave only enters the code some lane needs.
+// One pass of the helix loop (src/particle_loop.jl:154-499), organised for the hardware.
+// A lone wave issues one instruction per 4 cycles whatever its kind, and a conditional region
+// costs 4-5 instructions (v_cmp, s_and_saveexec, s_cbranch_execz, s_or) even when no lane takes
+// it, so the common step is straight-line code behind as few branches as possible:
+//   zone   a plain zone change (same flow speed on both sides): reload 1/(qB);
+//   pre    ONE branch for everything rare before the scatter: helix cap, Code Block 1 after a PRP
+//          return, frame transform at a flow-speed change, energy transfer, the three exit tests,
+//          radiative losses, refresh of the slowly varying scatter quantities;
+//   scatter + clock + pcut test: selects only;
+//   move   (refresh of t_step / 1/(gamma m) behind one branch), same-zone test;
+//   post   ONE branch for everything rare after the move (time-cut tally, no-DSA reflection,
+//          shock crossing, zone search + tally record, downstream test, PRP logic, retro walk).
 // The arithmetic and its order are those of the reference; only the control flow differs.
 // Returns -1 while the particle lives, else 0 = saved for the next pcut, 1..4 = i_reason.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p) {
   const double aa = h.aa;
-  int end = -1;
   p.helix += 1;
 
-  // ================= phase A =================
   const bool block1 = p.i_return == 1;
-  [[maybe_unused]] const unsigned long long pa0 = PROF_T();
+  const bool capped = p.helix > MCS_HELIX_CAP;
+  const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
+  // ================= zone change =================
+  bool need_xf = false;
+  if (!block1 && p.i_grid != p.ig3) {
+    need_xf = S_ux[p.i_grid] != S_ux[p.ig3];        // same u_x => no frame transform (particle_loop.jl:214)
+    if (!(need_xf | etf_ev | capped | h.custom_epsB)) {
+      p.ig3 = p.i_grid;
+      const double gd = S_gd[p.i_grid];             // == 1/(zz*btot[ig]), tabulated per zone
+      if (gd != p.gyro_denom) { p.gyro_denom = gd; p.dirty = DIRTY_S | DIRTY_M; }
+    }
+  }
+
+  // ================= pre: rare work before the scatter =================
   {
-    const bool capped = p.helix > MCS_HELIX_CAP;
-    const bool zone_ev = !block1 && (p.i_grid != p.ig3 || h.custom_epsB);
-    const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
-    PROF_LANES(13, capped | block1 | zone_ev | etf_ev);
-    if (capped | block1 | zone_ev | etf_ev) {
+    const bool rare_a = capped | block1 | need_xf | etf_ev | h.custom_epsB;
+    const bool rare_b = !block1 && ((p.ptot_pf > h.pmax_cutoff) | (p.inj && p.x < h.feb_up) |
+                                    (h.age_max > 0 && p.acctime > h.age_max) | ((p.dirty & DIRTY_S) != 0) |
+                                    (h.rad_losses && aa < 1) | h.dont_scatter);
+    PROF_LANES(13, rare_a | rare_b);
+    if (rare_a | rare_b) {
       PROF_ADD(12, 1);
       if (capped) {
         cnt(a, MCS_IC_HELIX_CAP);
-        end = 1;                                                      // quirk Q5
-      } else if (block1) {
+        return 1;                                                     // quirk Q5
+      }
+      if (block1) {
         // Code Block 1 (particle_loop.jl:167-177)
         p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
         p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
       } else {
-        // rare head of Code Block 3 (particle_loop.jl:186-246)
-        const int ig = p.i_grid, io = p.ig3;
-        p.ig3 = ig;
-        if (h.custom_epsB && p.x > h.x_grid_stop) {
-          const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-          p.gyro_denom = 1 / (h.zzq * bmag);
-        } else {
-          p.gyro_denom = S_gd[ig];            // == 1/(zz*btot[ig]), tabulated per zone
+        if (need_xf | etf_ev | h.custom_epsB) {
+          // rare head of Code Block 3 (particle_loop.jl:186-246)
+          const int ig = p.i_grid, io = p.ig3;
+          p.ig3 = ig;
+          if (h.custom_epsB && p.x > h.x_grid_stop) {
+            const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+            p.gyro_denom = 1 / (h.zzq * bmag);
+          } else {
+            p.gyro_denom = S_gd[ig];
+          }
+          if (ig != io && S_ux[ig] != S_ux[io]) {
+            const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
+            p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
+            p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+            p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+          }
+          if (etf_ev) {
+            Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+            r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
+            p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
+          }
+          p.dirty = DIRTY_S | DIRTY_M;
         }
-        if (ig != io && S_ux[ig] != S_ux[io]) {   // same zone => same u_x: no transform
-          const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
-          p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
-          p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+        // exit tests of Code Block 3 (particle_loop.jl:251-300), after the transforms
+        const int ig = p.ig3;
+        if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
+        if (p.ptot_pf > h.pmax_cutoff) {        // rare (only near p_max)
+          double ptot_sk, px, py, pz, gam_sk;
+          transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
+          if (ptot_sk > h.pmax_cutoff) return 2;
+        }
+        if (p.inj && p.x < h.feb_up) return 2;
+        if (h.age_max > 0 && p.acctime > h.age_max) return 3;
+        if (h.rad_losses && aa < 1) {
+          double bmag = S_bt[ig];
+          if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+          const double ptot_old = p.ptot_pf;
+          const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
+          p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, p.t_step);
+          if (p.ptot_pf <= 0) {
+            p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
+            return 4;
+          }
+          p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
+          p.pb_pf *= p.ptot_pf / ptot_old;
+          p.p_perp *= p.ptot_pf / ptot_old;
           p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+          p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+          p.dirty = DIRTY_S | DIRTY_M;
         }
-        if (etf_ev) {
-          Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
-          r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
-          p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
+        if ((p.dirty & DIRTY_S) && !h.dont_scatter) {
+          refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);
+          p.dirty &= ~DIRTY_S;
         }
       }
     }
   }
 
-  PROF_ADD(14, PROF_T() - pa0);
-  bool ev_tcut = false;
-  if (end < 0 && !block1) {
-    // ================= phase B, Code Block 3 (particle_loop.jl:251-385) =================
-    const int ig = p.ig3;
-    if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
-    if (p.ptot_pf > h.pmax_cutoff) {        // rare (only near p_max); after the transforms of phase A
-      double ptot_sk, px, py, pz, gam_sk;
-      transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
-      if (ptot_sk > h.pmax_cutoff) return 2;
+  // ================= scatter, clock, pcut test (Code Block 3, particle_loop.jl:327-385) =================
+  bool ev_tcut = false, saved = false;
+  if (!block1) {
+    if (!h.dont_scatter) scattering(rng, p, kc);
+    const bool ds = p.downstream;
+    const double acc_new = p.acctime + p.t_step * S_gef[p.ig3];
+    p.acctime = ds ? acc_new : p.acctime;
+    if (h.do_tcuts) {
+      // tcut_track! (cuts.jl:149-162) reads weight and ptot_pf, which the move does not change: the
+      // tally itself is deferred to the post block.  Past the last cut: D4 (counted, no tally).
+      const bool past = p.tcut > h.n_tcuts;
+      p.n_ovr += (ds && past) ? 1u : 0u;
+      ev_tcut = ds && !past && p.acctime >= p.tcut_next;
     }
-    if (p.inj && p.x < h.feb_up) return 2;
-    if (h.age_max > 0 && p.acctime > h.age_max) return 3;
-
-    if (h.rad_losses && aa < 1) {
-      double bmag = S_bt[ig];
-      if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-      const double ptot_old = p.ptot_pf;
-      const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
-      p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, p.t_step);
-      if (p.ptot_pf <= 0) {
-        p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
-        return 4;
-      }
-      p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
-      p.pb_pf *= p.ptot_pf / ptot_old;
-      p.p_perp *= p.ptot_pf / ptot_old;
-      p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
-      p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-    }
-
-    if (!h.dont_scatter) scattering(a, rng, p, aa, aa * MP_ * CC_, h.eta, kc);
-
-    if (p.downstream) {
-      p.acctime += p.t_step * S_gef[ig];
-      if (h.do_tcuts) {
-        // tcut_track! (cuts.jl:149-162) reads weight and ptot_pf, which the move does not change:
-        // the tally itself is deferred to phase C
-        if (p.tcut > h.n_tcuts) cnt(a, MCS_IC_TCUT_OVERRUN);   // D4
-        else ev_tcut = p.acctime >= p.tcut_next;
-      }
-      if (p.ptot_pf > h.pcut) end = 0;   // saved for the next pcut (particle_loop.jl:361-380): no move
-    }
-    if (end < 0) {
-      const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
-      if (xn != p.xn_per) { p.xn_per = xn; p.dphi = TWOPI_ / xn; p.gp_key = -1.0; }
-    }
+    saved = ds && p.ptot_pf > h.pcut;     // saved for the next pcut (particle_loop.jl:361-380): no move
+    const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
+    const bool xn_ch = !saved && xn != p.xn_per;
+    p.xn_per = xn_ch ? xn : p.xn_per;
+    p.dirty = xn_ch ? (DIRTY_S | DIRTY_M) : p.dirty;
   }
-
-  // the saved particle's time-cut tally still has to happen (it precedes the save in the reference)
-  if (end == 0) {
+  if (saved) {
+    // the saved particle's time-cut tally still has to happen (it precedes the save in the reference)
     if (ev_tcut) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
     return 0;
   }
-  if (end > 0) return end;
 
   // ================= phase B, Code Block 2: the move (particle_loop.jl:392-407, 510-571) =================
   const int ig3 = p.ig3;
   const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
   p.x_old = p.x;
   const double phi_old = p.phi;
-  if (p.gyro_period != p.gp_key) { p.t_step = p.gyro_period / p.xn_per; p.gp_key = p.gyro_period; }
+  if (p.dirty & DIRTY_M) {     // t_step, 2pi/xn_per and 1/(gamma m): particle_loop.jl:400,529,531
+    p.dphi = TWOPI_ / p.xn_per;
+    p.t_step = p.gyro_period / p.xn_per;
+    p.rg_val = rcp_refined(p.gam_pf * (aa * MP_));
+    p.dirty &= ~DIRTY_M;
+  }
   bool ev_reflect;
   {
     const double m = aa * MP_;
     p.phi = mcsm::mod2pi(p.phi + p.dphi);
     const double gm = p.gam_pf * m;
-    if (p.gam_pf != p.rg_key) { p.rg_val = rcp_refined(gm); p.rg_key = p.gam_pf; }
     const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
     double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
     if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
@@ -862,9 +906,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
   if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
   p.i_return = 2;                                             // prob_return's default (prob_return.jl:48)
 
-  // ================= phase C =================
-  [[maybe_unused]] const unsigned long long pc0 = PROF_T();
-  PROF_ADD(26, pc0 - pa0);    // phases A+B (lanes that reach the move)
+  // ================= post: rare work after the move =================
   PROF_LANES(16, ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp);
   PROF_LANES(22, ev_flux); PROF_LANES(23, ev_dtest); PROF_LANES(24, ev_prp); PROF_LANES(25, ev_tcut);
   if (ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp) {
@@ -952,7 +994,6 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
       return lose_pt ? 4 : 1;
     }
   }
-  PROF_ADD(17, PROF_T() - pc0);
   return -1;
 }
 
@@ -1088,6 +1129,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
         PROF_ADD(10, 1);
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
+        if (p.n_ovr) cnt(a, MCS_IC_TCUT_OVERRUN, p.n_ovr);
         if (end == 0) {
           a->l_save[k] = 1;
           a->sv.weight[k] = p.weight; a->sv.ptot_pf[k] = p.ptot_pf; a->sv.pb_pf[k] = p.pb_pf; a->sv.x_PT_cm[k] = p.x;
