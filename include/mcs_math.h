@@ -121,7 +121,7 @@ MCS_HD double cos(double x) { double s, c; sincos(x, &s, &c); return c; }
 /* Base.mod2pi for the bounded phase angles of the path (|x| < ~1e5). */
 MCS_HD double mod2pi(double x) {
   double r = x;
-  if (!(r >= 0.0 && r < MCS_TWOPI)) {
+  if (__builtin_expect(!(r >= 0.0 && r < MCS_TWOPI), 0)) {
     double k = __builtin_floor(x * MCS_INV_TWOPI);
     r = fma_(-k, MCS_SC(MCS_TWOPI_DD_0), x);
     r = fma_(-k, MCS_SC(MCS_TWOPI_DD_1), r);

@@ -113,10 +113,15 @@ __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
 
 // Per-particle stream: draw j -> words (2*(j&1), 2*(j&1)+1) of block j>>1.  The odd
 // draw of a block is kept in a register so that two consecutive draws cost one block.
+// (Computing the next step's block one step ahead -- off the critical path -- was tried and
+// gained nothing: hipcc does not interleave it with the fp64 chain under this register pressure.)
 struct Rng {
   uint32_t k0, k1;
   uint32_t n;        // draws so far (a history makes < 2^32 draws)
   double spare;
+  __device__ __forceinline__ void init(unsigned long long key) {
+    k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); n = 0; spare = 0.0;
+  }
   __device__ __forceinline__ double rand() {
     const uint32_t j = n++;
     if (j & 1u) return spare;
@@ -132,14 +137,6 @@ struct Rng {
     n = j + 2u;
     uint32_t o0, o1, o2, o3;
     philox_block((j + 1u) >> 1, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
-#ifdef MCS_PHILOX_DOUBLE   /* TIMING EXPERIMENT: a second, dependent block whose result is discarded */
-    {
-      uint32_t q0, q1, q2, q3, z;
-      philox_block(o0, o1, o2, o3, k0, k1, q0, q1, q2, q3);
-      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-      o0 ^= (q0 ^ q1 ^ q2 ^ q3) & z;
-    }
-#endif
     const double a = u64_to_unit(o0, o1), b = u64_to_unit(o2, o3);
     const bool odd = (j & 1u) != 0u;
     u1 = odd ? spare : a;
@@ -173,6 +170,9 @@ struct Lds {                                // kept as an (empty) handle so call
 // The zone properties "of the current pass" (ux, uz, utot, gamma_sf, gamma_ef, sin/cos
 // theta_B; particle_loop.jl:195-204) are the LDS table entries of zone `ig3`, the zone the
 // particle was in when Code Block 3 last ran; they are re-read from LDS where needed.
+// Rare regions: the hint lets block placement move their bodies out of line, so the common step
+// falls through its branches (a taken branch refills the instruction buffer).
+#define MCS_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #define DIRTY_S 1
 #define DIRTY_M 2
 struct Pt {
@@ -187,6 +187,7 @@ struct Pt {
   double cm_val;                 // cos_max of the scattering cone (scattering.jl:60)   (DIRTY_S)
   double rg_val;                 // refined 1/(gam_pf*m)                    (DIRTY_M, before the move)
   double tcut_next;              // tcuts[tcut-1] (LDS) or +inf
+  double x_dt;                   // downstream_test exit threshold (refresh_dtest)
   int dirty;                     // DIRTY_S | DIRTY_M
   unsigned n_ovr;                // steps taken past the last time cut (D4 counter, flushed at the end)
   int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
@@ -715,7 +716,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.ig3 = p.i_grid;
   p.helix = 0; p.n_retro = 0;
   const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
-  rng.k0 = (uint32_t)key; rng.k1 = (uint32_t)(key >> 32); rng.n = 0; rng.spare = 0.0;
+  rng.init(key);
 
   p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
   p.gyro_denom = S_gd[p.i_grid];
@@ -729,10 +730,44 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? S_tc[p.tcut - 1] : __builtin_inf();
-  p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0;
+  p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
   p.dirty = DIRTY_S | DIRTY_M;
   p.n_ovr = 0u;
   p.pushed = false;
+}
+
+// Zone-crossing tallies do not feed back into the particle: the lane pushes a record on its wave's
+// LDS stack (see S_evf) instead of tallying on the spot.  The stack cannot overflow: it is drained
+// to < 64 at the top of every pass and one pass adds at most one record per lane.
+__device__ __forceinline__ void push_record(Pt& p, int ig3) {
+  const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
+  const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+  const unsigned base = S_evcur[wv];
+  const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
+  S_evf[wv][0][pos] = p.pb_pf; S_evf[wv][1][pos] = p.p_perp; S_evf[wv][2][pos] = p.ptot_pf; S_evf[wv][3][pos] = p.gam_pf;
+  S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
+  S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
+  if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
+  p.pushed = true;
+}
+
+// downstream_test (particle_loop.jl:595-637) ends a particle iff  x > feb_downstream (when set)  or
+// (x > 1.1 prp  and  x > 6.91 L_diff).  x_dt is that threshold, min(feb, max(1.1 prp, 6.91 L_diff)): a
+// function of (prp, ptot_pf, gam_pf, gyro_rad_tot, gyro_denom), refreshed whenever one of them changed.
+__device__ __forceinline__ void refresh_dtest(CK* a, const Hot& h, Pt& p) {
+  const double aa = h.aa, m = aa * MP_;
+  double v_fac;
+  if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
+    const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
+    v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
+  } else {
+    v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
+  }
+  const double L_diff = h.eta / 3 * v_fac;
+  const double t1 = 1.1 * p.prp, t2 = 6.91 * L_diff;
+  double t = t1 > t2 ? t1 : t2;
+  if (h.feb_down > 0 && h.feb_down < t) t = h.feb_down;
+  p.x_dt = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -760,7 +795,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
   const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
   // ================= zone change =================
   bool need_xf = false;
-  if (!block1 && p.i_grid != p.ig3) {
+  if (MCS_UNLIKELY(!block1 && p.i_grid != p.ig3)) {
     need_xf = S_ux[p.i_grid] != S_ux[p.ig3];        // same u_x => no frame transform (particle_loop.jl:214)
     if (!(need_xf | etf_ev | capped | h.custom_epsB)) {
       p.ig3 = p.i_grid;
@@ -776,7 +811,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
                                     (h.age_max > 0 && p.acctime > h.age_max) | ((p.dirty & DIRTY_S) != 0) |
                                     (h.rad_losses && aa < 1) | h.dont_scatter);
     PROF_LANES(13, rare_a | rare_b);
-    if (rare_a | rare_b) {
+    if (MCS_UNLIKELY(rare_a | rare_b)) {
       PROF_ADD(12, 1);
       if (capped) {
         cnt(a, MCS_IC_HELIX_CAP);
@@ -837,8 +872,9 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
           p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
           p.dirty = DIRTY_S | DIRTY_M;
         }
-        if ((p.dirty & DIRTY_S) && !h.dont_scatter) {
-          refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);
+        if (p.dirty & DIRTY_S) {
+          if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);
+          refresh_dtest(a, h, p);
           p.dirty &= ~DIRTY_S;
         }
       }
@@ -865,7 +901,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
     p.xn_per = xn_ch ? xn : p.xn_per;
     p.dirty = xn_ch ? (DIRTY_S | DIRTY_M) : p.dirty;
   }
-  if (saved) {
+  if (MCS_UNLIKELY(saved)) {
     // the saved particle's time-cut tally still has to happen (it precedes the save in the reference)
     if (ev_tcut) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
     return 0;
@@ -876,7 +912,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
   const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
   p.x_old = p.x;
   const double phi_old = p.phi;
-  if (p.dirty & DIRTY_M) {     // t_step, 2pi/xn_per and 1/(gamma m): particle_loop.jl:400,529,531
+  if (MCS_UNLIKELY(p.dirty & DIRTY_M)) {     // t_step, 2pi/xn_per and 1/(gamma m): particle_loop.jl:400,529,531
     p.dphi = TWOPI_ / p.xn_per;
     p.t_step = p.gyro_period / p.xn_per;
     p.rg_val = rcp_refined(p.gam_pf * (aa * MP_));
@@ -889,7 +925,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
     const double gm = p.gam_pf * m;
     const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
     double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
-    if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+    if (MCS_UNLIKELY(bsin != 0.0)) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
     const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
     p.x = p.x_old + dx;
     ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1);
@@ -899,18 +935,36 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
   const bool fwd = p.x > p.x_old;
   const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
   const bool ev_shock = p.x_old < 0 && p.x >= 0;
-  const bool ev_flux = !same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0;
-  const bool ev_dtest = (h.feb_down > 0 && p.x > h.feb_down) || p.x > 1.1 * p.prp;
+  // downstream_test (particle_loop.jl:595-637) can only end the particle beyond x_dt (see refresh_dtest)
+  const bool ev_dt = p.x > p.x_dt;
   const bool ev_prp = p.x >= h.x_grid_stop &&
                       (p.x_old < h.x_grid_stop || (p.x_old < p.prp && p.x >= p.prp) || aa < 1);
   if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
   p.i_return = 2;                                             // prob_return's default (prob_return.jl:48)
+  const bool ev_other = ev_tcut | ev_reflect | ev_shock | ev_dt | ev_prp;
+  bool ev_flux = (!same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0) && ev_other;
+
+  // ================= plain zone crossing: into the neighbouring zone, nothing else going on =================
+  if (MCS_UNLIKELY(!same_zone && !ev_other)) {
+    const int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
+    // all_flux!'s search (all_flux.jl:68-72) stops at the neighbour iff its far edge is beyond x
+    const bool adjacent = fwd ? (cand + 1 < h.n_grid + 2 && S_x[cand + 1] > p.x) : (cand >= 0 && S_x[cand] <= p.x);
+    if (adjacent) {
+      p.i_grid = cand;
+      push_record(p, ig3);
+    } else {
+      ev_flux = true;      // several zones in one step, or off the grid: the search loop of the post block
+    }
+  } else if (same_zone && !ev_other && (p.i_grid <= h.i_grid_feb || h.n_xspec != 0)) {
+    ev_flux = true;
+  }
 
   // ================= post: rare work after the move =================
-  PROF_LANES(16, ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp);
-  PROF_LANES(22, ev_flux); PROF_LANES(23, ev_dtest); PROF_LANES(24, ev_prp); PROF_LANES(25, ev_tcut);
-  if (ev_tcut | ev_reflect | ev_shock | ev_flux | ev_dtest | ev_prp) {
+  PROF_LANES(16, ev_other | ev_flux);
+  PROF_LANES(22, ev_flux); PROF_LANES(23, ev_dt); PROF_LANES(24, ev_prp); PROF_LANES(25, ev_tcut);
+  if (MCS_UNLIKELY(ev_other | ev_flux)) {
     PROF_ADD(15, 1);
+    [[maybe_unused]] const unsigned long long pc0 = PROF_T();
     if (ev_tcut) {
       tcut_track(a, p.tcut, p.weight, p.ptot_pf);
       p.tcut += 1;
@@ -951,18 +1005,7 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
       if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) {
-        // Tallies do not feed back into the particle: push a record (see S_evf).  The stack
-        // cannot overflow: it is drained to < 64 at the top of every pass and one pass adds
-        // at most one record per lane.
-        const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
-        const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-        const unsigned base = S_evcur[wv];
-        const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
-        S_evf[wv][0][pos] = p.pb_pf; S_evf[wv][1][pos] = p.p_perp; S_evf[wv][2][pos] = p.ptot_pf; S_evf[wv][3][pos] = p.gam_pf;
-        S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
-        S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
-        if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
-        p.pushed = true;
+        push_record(p, ig3);
         PROF_ADD(19, 1); PROF_LANES(18, true);
       }
     }
@@ -993,6 +1036,8 @@ __device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, con
       sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
       return lose_pt ? 4 : 1;
     }
+    refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
+    PROF_ADD(17, PROF_T() - pc0);
   }
   return -1;
 }
@@ -1084,12 +1129,12 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     [[maybe_unused]] const unsigned long long pt0 = PROF_T();
     ev_pending += (unsigned)__popcll(__ballot(p.pushed));
     p.pushed = false;
-    if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
+    if (MCS_UNLIKELY(ev_pending >= 64u)) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
     [[maybe_unused]] const unsigned long long pt1 = PROF_T();
     PROF_ADD(2, pt1 - pt0);
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
-    if (idle != 0ull && !exhausted) {
+    if (MCS_UNLIKELY(idle != 0ull && !exhausted)) {
       const int nidle = __popcll(idle);
       const int leader = __ffsll((long long)idle) - 1;
       unsigned long long base = 0;
@@ -1115,7 +1160,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
       PROF_ADD(0, 1); PROF_ADD(8, na__);
       if (na__ <= 8) PROF_ADD(21, 1);
     }
-    if (__ballot(active) == 0ull) {
+    if (MCS_UNLIKELY(__ballot(active) == 0ull)) {
       if (exhausted) break;
       continue;
     }
@@ -1125,7 +1170,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     PROF_ADD(7, pt3 - pt2);
     PROF_LANES(11, active && end >= 0);
     if (active) {
-      if (end >= 0) {
+      if (MCS_UNLIKELY(end >= 0)) {
         PROF_ADD(10, 1);
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
