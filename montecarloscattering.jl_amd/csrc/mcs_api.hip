@@ -287,6 +287,20 @@ int mcs_set_grid(mcs_ctx* c, int n_entries, const double* x_grid_cm, const doubl
     if (!std::isfinite(x_grid_cm[i])) return fail("mcs_set_grid: x_grid_cm must be finite (use +-1e30*rg0 sentinels)");
   }
   (void)beta_ef;  // passed by the reference (main_loops.jl:256) but never read by the path
+  // The kernel detects "something happened at this move" by zone changes, so two facts of the
+  // reference's grid are relied upon (setup_grid, src/initializers.jl:403-476): the shock x = 0 is a
+  // zone boundary, and the upstream FEB lies inside zone i_grid_feb (MonteCarloScattering.jl:414).
+  {
+    bool has_zero = false;
+    for (int i = 0; i < ne; ++i) {
+      if (x_grid_cm[i] == 0.0) has_zero = true;
+      if (i > 0 && !(x_grid_cm[i] > x_grid_cm[i - 1])) return fail("mcs_set_grid: x_grid_cm must be strictly increasing");
+    }
+    if (!has_zero) return fail("mcs_set_grid: x_grid_cm must contain the shock position 0.0 as a zone boundary");
+    const int k = c->P.i_grid_feb;
+    if (k < 0 || k + 1 >= ne || !(x_grid_cm[k + 1] > c->P.feb_upstream))
+      return fail("mcs_set_grid: feb_upstream must lie below x_grid_cm[i_grid_feb+1]");
+  }
   const double* src[8] = {x_grid_cm, ux, uz, utot, gam_sf, gam_ef, btot, theta};
   std::vector<double> h((size_t)8 * ne);
   for (int t = 0; t < 8; ++t) std::memcpy(&h[(size_t)t * ne], src[t], (size_t)ne * sizeof(double));

@@ -173,24 +173,35 @@ struct Lds {                                // kept as an (empty) handle so call
 // Rare regions: the hint lets block placement move their bodies out of line, so the common step
 // falls through its branches (a taken branch refills the instruction buffer).
 #define MCS_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#define DIRTY_S 1
-#define DIRTY_M 2
+
+// Per-particle flags (Pt::flags).  Any bit set sends the lane through the rare block before its
+// next step; the bits are set where the underlying quantity changes (always in rare code), so the
+// common step tests ONE register instead of re-evaluating a dozen conditions.
+#define F_RS      0x001   // scatter-side derived quantities are stale (cm_val, rp_val, gyro_period, x_dt, F_NEARP, F_SAVE)
+#define F_RM      0x002   // move-side derived quantities are stale (t_step, dphi, rg_val)
+#define F_ZONE    0x004   // i_grid != ig3: Code Block 3 has to reload the zone (particle_loop.jl:186-246)
+#define F_B1      0x008   // next pass is Code Block 1 (i_return == 1 after a PRP return, particle_loop.jl:167-177)
+#define F_NEARP   0x010   // ptot_pf > pmax_cutoff: the p_max exit needs its transform (particle_loop.jl:264)
+#define F_NEARFEB 0x020   // i_grid <= i_grid_feb: FEB exit test and all_flux's upstream special case every pass
+#define F_SAVE    0x040   // downstream && ptot_pf > pcut: saved for the next pcut at the next Code Block 3
+#define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
+#define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
-  double dphi;                   // 2pi / xn_per, recomputed only when xn_per changes (particle_loop.jl:529)
+  double dphi;                   // 2pi / xn_per (particle_loop.jl:529)
   double gyro_denom, gyro_rad, gyro_rad_tot, gyro_period, t_step;
-  // Values that are pure functions of (ptot_pf, gam_pf, gyro_denom, xn_per) and therefore change
-  // only at rare events (frame transform at the shock, energy transfer, radiative loss, PRP return,
-  // field change, fine/coarse switch).  Every such event sets `dirty`; the values are recomputed
-  // -- with the reference's own expressions, so bit-identically -- before their next use:
-  double rp_val;                 // refined 1/ptot_pf                       (DIRTY_S, before the scatter)
-  double cm_val;                 // cos_max of the scattering cone (scattering.jl:60)   (DIRTY_S)
-  double rg_val;                 // refined 1/(gam_pf*m)                    (DIRTY_M, before the move)
-  double tcut_next;              // tcuts[tcut-1] (LDS) or +inf
+  // Pure functions of (ptot_pf, gam_pf, gyro_denom, xn_per, prp), which change only in rare code
+  // (frame transform at the shock, energy transfer, radiative loss, PRP logic, field change,
+  // fine/coarse switch).  Recomputed there with the reference's own expressions: bit-identical.
+  double rp_val;                 // refined 1/ptot_pf
+  double cm_val;                 // cos_max of the scattering cone (scattering.jl:60)
+  double rg_val;                 // refined 1/(gam_pf*m)
   double x_dt;                   // downstream_test exit threshold (refresh_dtest)
-  int dirty;                     // DIRTY_S | DIRTY_M
-  unsigned n_ovr;                // steps taken past the last time cut (D4 counter, flushed at the end)
-  int i_grid, i_grid_old, ig3, helix, tcut, i_return, n_retro;
+  double t_ev;                   // min(next time cut, age_max): the clock compares against one number
+  int flags;
+  int ovr_inc;                   // 1 while downstream past the last time cut (D4 counter), else 0
+  unsigned n_ovr;                // passes counted by D4, flushed when the particle ends
+  int i_grid, i_grid_old, ig3, helix, tcut, n_retro;
   bool downstream, inj;
   bool pushed;                   // this lane pushed a tally record in the current pass
 };
@@ -567,10 +578,15 @@ __device__ __forceinline__ int vconsti(int x) { asm volatile("" : "+v"(x)); retu
 
 // hot-loop constants, fetched once per wave and parked in VGPRs (see the kernel prologue)
 struct Hot {
-  double aa, m, mc, zzq, pcut, pmax_cutoff, feb_up, feb_down, age_max, x_grid_stop, u2, eta, xn_fine, xn_coarse, inj_frac;
-  int n_grid, i_grid_feb, n_tcuts, n_xspec;
-  bool custom_epsB, etf, dont_scatter, rad_losses, do_tcuts, dont_DSA;
+  double m, x_grid_stop, xn_coarse;     // used by every pass: parked in VGPRs
+  bool custom_epsB, etf, dont_scatter, rad_losses, do_tcuts, dont_DSA;   // wave-uniform flags (scalar branches)
+  bool oblique;     // some zone has b_sin != 0 (the gyro term of the move is not identically zero)
+  bool odd_cfg;     // downstream FEB, no-DSA / injection probability, electrons or x_spec detectors: extra per-pass tests
+  bool every_pass;  // custom eps_B, radiative losses of electrons, no-scatter runs: slow_pre has work in every pass
 };
+// Everything else is read from the launch constants (constant address space: s_load) where the rare
+// code needs it, instead of occupying registers for the whole loop.
+
 
 // src/particle_loop.jl:652-723
 __device__ MCS_COLD Mom do_energy_transfer(CK* a, int i_grid, int i_grid_old, double weight, Mom r) {
@@ -649,11 +665,23 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
   }
 }
 
+// tcuts[tcut-1] or +inf past the last cut (D4)
+__device__ __forceinline__ double tcut_next_of(CK* a, const Hot& h, int tcut) {
+  return (h.do_tcuts && tcut <= a->tb.n_tcuts) ? S_tc[tcut - 1] : __builtin_inf();
+}
+// The clock compares acctime with ONE number: the earlier of the next time cut and age_max.
+__device__ __forceinline__ void refresh_time(CK* a, const Hot& h, Pt& p) {
+  double t = tcut_next_of(a, h, p.tcut);
+  if (a->P.age_max > 0 && a->P.age_max < t) t = a->P.age_max;
+  p.t_ev = t;
+  p.ovr_inc = (h.do_tcuts && p.downstream && p.tcut > a->tb.n_tcuts) ? 1 : 0;
+}
+
 // src/prob_return.jl:36-173, entered only when it has something to do (the caller has
 // already set i_return = 2 and filtered the no-op cases).
-__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, bool& lose_pt) {
+__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt) {
   const auto& P = a->P;
-  const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
+  const double aa = a->aa, u2 = a->P.u2, eta = a->P.eta_mfp, x_grid_stop = h.x_grid_stop;
   if (p.x < x_grid_stop) {
   } else if (p.x_old < x_grid_stop && x_grid_stop <= p.x) {
     double gyro_tmp;
@@ -666,19 +694,19 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
     const double q = (vt - u2) / (vt + u2);
     const double prob_ret = q * q;
     if (vt < u2 || rng.rand() > prob_ret) {
-      p.i_return = 0;
+      i_return = 0;
     } else {
-      p.i_return = 1;
+      i_return = 1;
       Retro r;
       r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
-      r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = p.tcut_next; r.tcut = p.tcut;
+      r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = tcut_next_of(a, h, p.tcut); r.tcut = p.tcut;
       r.n_retro = p.n_retro; r.rng_n = rng.n; r.rng_spare = rng.spare; r.lose_pt = false;
       r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
-      p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut_next = r.tcut_next; p.tcut = r.tcut;
+      p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut = r.tcut;
       p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
-      p.dirty = DIRTY_S | DIRTY_M;     // radiative losses inside the walk change ptot_pf / gam_pf
-      if (lose_pt) p.i_return = 0;
+      p.flags |= F_RS | F_RM;          // radiative losses inside the walk change ptot_pf / gam_pf
+      if (lose_pt) i_return = 0;
       p.x = p.prp;
     }
   } else {
@@ -718,21 +746,20 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
   rng.init(key);
 
-  p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
+  p.gam_pf = mcsm::hypot1(p.ptot_pf / a->mc);
   p.gyro_denom = S_gd[p.i_grid];
   if (h.custom_epsB && p.x > h.x_grid_stop) p.gyro_denom *= __builtin_sqrt(p.x / h.x_grid_stop);
   p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
   p.gyro_period = TWOPI_ * p.gam_pf * h.m * CC_ * p.gyro_denom;
-  p.i_return = -1;
   p.t_step = 0.0;
   p.dphi = TWOPI_ / p.xn_per;
   p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
-  p.tcut_next = (h.do_tcuts && p.tcut <= h.n_tcuts) ? S_tc[p.tcut - 1] : __builtin_inf();
   p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
-  p.dirty = DIRTY_S | DIRTY_M;
+  p.flags = F_RS | F_RM | (p.i_grid <= a->P.i_grid_feb ? F_NEARFEB : 0);
   p.n_ovr = 0u;
+  refresh_time(a, h, p);
   p.pushed = false;
 }
 
@@ -755,291 +782,314 @@ __device__ __forceinline__ void push_record(Pt& p, int ig3) {
 // (x > 1.1 prp  and  x > 6.91 L_diff).  x_dt is that threshold, min(feb, max(1.1 prp, 6.91 L_diff)): a
 // function of (prp, ptot_pf, gam_pf, gyro_rad_tot, gyro_denom), refreshed whenever one of them changed.
 __device__ __forceinline__ void refresh_dtest(CK* a, const Hot& h, Pt& p) {
-  const double aa = h.aa, m = aa * MP_;
+  const double aa = a->aa, m = aa * MP_;
   double v_fac;
   if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
     const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
-    v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
+    v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * a->P.u2);
   } else {
-    v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
+    v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * a->P.u2);
   }
-  const double L_diff = h.eta / 3 * v_fac;
+  const double L_diff = a->P.eta_mfp / 3 * v_fac;
   const double t1 = 1.1 * p.prp, t2 = 6.91 * L_diff;
   double t = t1 > t2 ? t1 : t2;
-  if (h.feb_down > 0 && h.feb_down < t) t = h.feb_down;
+  if (a->P.feb_downstream > 0 && a->P.feb_downstream < t) t = a->P.feb_downstream;
   p.x_dt = t;
 }
 
 // ------------------------------------------------------------------------------------------
-// One pass of the helix loop (src/particle_loop.jl:154-499), organised for the hardware.
-// A lone wave issues one instruction per 4 cycles whatever its kind, and a conditional region
-// costs 4-5 instructions (v_cmp, s_and_saveexec, s_cbranch_execz, s_or) even when no lane takes
-// it, so the common step is straight-line code behind as few branches as possible:
-//   zone   a plain zone change (same flow speed on both sides): reload 1/(qB);
-//   pre    ONE branch for everything rare before the scatter: helix cap, Code Block 1 after a PRP
-//          return, frame transform at a flow-speed change, energy transfer, the three exit tests,
-//          radiative losses, refresh of the slowly varying scatter quantities;
-//   scatter + clock + pcut test: selects only;
-//   move   (refresh of t_step / 1/(gamma m) behind one branch), same-zone test;
-//   post   ONE branch for everything rare after the move (time-cut tally, no-DSA reflection,
-//          shock crossing, zone search + tally record, downstream test, PRP logic, retro walk).
+// The helix loop (src/particle_loop.jl:154-499), organised for the hardware.
+//
+// Measured on gfx950 (tools/ubench/lat.hip): a lone wave issues one instruction per 4 cycles,
+// dependent or not, and every conditional region costs ~36 cycles even when no lane takes it
+// (v_cmp -> SALU -> exec round trip).  So the common pass is straight-line code, executed by all
+// lanes, with every rare thing -- before or after the move -- funnelled through ONE region:
+//
+//   loop:  [rare(lane)  if the lane has an event pending or a flag set]     <- the only exec branch
+//          fast_step    scatter, clock, move, event detection                 (selects only)
+//
+//   rare = slow_post   everything the last move triggered (time-cut tally, no-DSA reflection, shock
+//                      crossing, zone search + tally record, downstream test, PRP logic, retro walk)
+//          block1_step Code Block 1 passes after a PRP return (no scatter: done here, move included)
+//          slow_pre    everything before the next scatter (helix cap, zone reload, frame transform,
+//                      energy transfer, the exit tests, radiative losses, refresh of the slowly
+//                      varying quantities, fine/coarse switch, the save for the next pcut)
+//          finish      tallies / saved-array writes of a particle that ended
+//
 // The arithmetic and its order are those of the reference; only the control flow differs.
-// Returns -1 while the particle lives, else 0 = saved for the next pcut, 1..4 = i_reason.
+// End codes: 0 = saved for the next pcut, 1..4 = i_reason.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int helix_step(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p) {
-  const double aa = h.aa;
-  p.helix += 1;
 
-  const bool block1 = p.i_return == 1;
-  const bool capped = p.helix > MCS_HELIX_CAP;
-  const bool etf_ev = !block1 && h.etf && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
-  // ================= zone change =================
-  bool need_xf = false;
-  if (MCS_UNLIKELY(!block1 && p.i_grid != p.ig3)) {
-    need_xf = S_ux[p.i_grid] != S_ux[p.ig3];        // same u_x => no frame transform (particle_loop.jl:214)
-    if (!(need_xf | etf_ev | capped | h.custom_epsB)) {
-      p.ig3 = p.i_grid;
-      const double gd = S_gd[p.i_grid];             // == 1/(zz*btot[ig]), tabulated per zone
-      if (gd != p.gyro_denom) { p.gyro_denom = gd; p.dirty = DIRTY_S | DIRTY_M; }
-    }
-  }
-
-  // ================= pre: rare work before the scatter =================
-  {
-    const bool rare_a = capped | block1 | need_xf | etf_ev | h.custom_epsB;
-    const bool rare_b = !block1 && ((p.ptot_pf > h.pmax_cutoff) | (p.inj && p.x < h.feb_up) |
-                                    (h.age_max > 0 && p.acctime > h.age_max) | ((p.dirty & DIRTY_S) != 0) |
-                                    (h.rad_losses && aa < 1) | h.dont_scatter);
-    PROF_LANES(13, rare_a | rare_b);
-    if (MCS_UNLIKELY(rare_a | rare_b)) {
-      PROF_ADD(12, 1);
-      if (capped) {
-        cnt(a, MCS_IC_HELIX_CAP);
-        return 1;                                                     // quirk Q5
-      }
-      if (block1) {
-        // Code Block 1 (particle_loop.jl:167-177)
-        p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
-        p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-      } else {
-        if (need_xf | etf_ev | h.custom_epsB) {
-          // rare head of Code Block 3 (particle_loop.jl:186-246)
-          const int ig = p.i_grid, io = p.ig3;
-          p.ig3 = ig;
-          if (h.custom_epsB && p.x > h.x_grid_stop) {
-            const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-            p.gyro_denom = 1 / (h.zzq * bmag);
-          } else {
-            p.gyro_denom = S_gd[ig];
-          }
-          if (ig != io && S_ux[ig] != S_ux[io]) {
-            const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
-            p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
-            p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-            p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
-          }
-          if (etf_ev) {
-            Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
-            r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
-            p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
-          }
-          p.dirty = DIRTY_S | DIRTY_M;
-        }
-        // exit tests of Code Block 3 (particle_loop.jl:251-300), after the transforms
-        const int ig = p.ig3;
-        if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.i_return = 0; return 1; }
-        if (p.ptot_pf > h.pmax_cutoff) {        // rare (only near p_max)
-          double ptot_sk, px, py, pz, gam_sk;
-          transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
-          if (ptot_sk > h.pmax_cutoff) return 2;
-        }
-        if (p.inj && p.x < h.feb_up) return 2;
-        if (h.age_max > 0 && p.acctime > h.age_max) return 3;
-        if (h.rad_losses && aa < 1) {
-          double bmag = S_bt[ig];
-          if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-          const double ptot_old = p.ptot_pf;
-          const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
-          p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, p.t_step);
-          if (p.ptot_pf <= 0) {
-            p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
-            return 4;
-          }
-          p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
-          p.pb_pf *= p.ptot_pf / ptot_old;
-          p.p_perp *= p.ptot_pf / ptot_old;
-          p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
-          p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
-          p.dirty = DIRTY_S | DIRTY_M;
-        }
-        if (p.dirty & DIRTY_S) {
-          if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);
-          refresh_dtest(a, h, p);
-          p.dirty &= ~DIRTY_S;
-        }
-      }
-    }
-  }
-
-  // ================= scatter, clock, pcut test (Code Block 3, particle_loop.jl:327-385) =================
-  bool ev_tcut = false, saved = false;
-  if (!block1) {
-    if (!h.dont_scatter) scattering(rng, p, kc);
-    const bool ds = p.downstream;
-    const double acc_new = p.acctime + p.t_step * S_gef[p.ig3];
-    p.acctime = ds ? acc_new : p.acctime;
-    if (h.do_tcuts) {
-      // tcut_track! (cuts.jl:149-162) reads weight and ptot_pf, which the move does not change: the
-      // tally itself is deferred to the post block.  Past the last cut: D4 (counted, no tally).
-      const bool past = p.tcut > h.n_tcuts;
-      p.n_ovr += (ds && past) ? 1u : 0u;
-      ev_tcut = ds && !past && p.acctime >= p.tcut_next;
-    }
-    saved = ds && p.ptot_pf > h.pcut;     // saved for the next pcut (particle_loop.jl:361-380): no move
-    const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
-    const bool xn_ch = !saved && xn != p.xn_per;
-    p.xn_per = xn_ch ? xn : p.xn_per;
-    p.dirty = xn_ch ? (DIRTY_S | DIRTY_M) : p.dirty;
-  }
-  if (MCS_UNLIKELY(saved)) {
-    // the saved particle's time-cut tally still has to happen (it precedes the save in the reference)
-    if (ev_tcut) { tcut_track(a, p.tcut, p.weight, p.ptot_pf); p.tcut += 1; }
-    return 0;
-  }
-
-  // ================= phase B, Code Block 2: the move (particle_loop.jl:392-407, 510-571) =================
+// Code Block 2, the move (particle_loop.jl:392-407, 510-538) and the detection of everything that
+// needs slow_post.  Straight-line; `oblique` is wave-uniform (some zone has b_sin != 0).
+__device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross) {
   const int ig3 = p.ig3;
-  const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
+  const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], ux = S_ux[ig3];
   p.x_old = p.x;
   const double phi_old = p.phi;
-  if (MCS_UNLIKELY(p.dirty & DIRTY_M)) {     // t_step, 2pi/xn_per and 1/(gamma m): particle_loop.jl:400,529,531
-    p.dphi = TWOPI_ / p.xn_per;
-    p.t_step = p.gyro_period / p.xn_per;
-    p.rg_val = rcp_refined(p.gam_pf * (aa * MP_));
-    p.dirty &= ~DIRTY_M;
+  phi_old_out = phi_old;
+  p.phi = mcsm::mod2pi(p.phi + p.dphi);
+  const double gm = p.gam_pf * h.m;
+  const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
+  double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
+  if (h.oblique) {
+    const double bsin = S_bsin[ig3];
+    const double g = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+    gyr = bsin != 0.0 ? g : 0.0;
   }
-  bool ev_reflect;
-  {
-    const double m = aa * MP_;
-    p.phi = mcsm::mod2pi(p.phi + p.dphi);
-    const double gm = p.gam_pf * m;
-    const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
-    double gyr = 0.0;   // gyro_rad*b_sin*(...) is exactly +-0 for a parallel field (b_sin == 0)
-    if (MCS_UNLIKELY(bsin != 0.0)) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
-    const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
-    p.x = p.x_old + dx;
-    ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1);
-  }
+  const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
+  p.x = p.x_old + dx;
   // same-zone test (all_flux.jl:64-82): one boundary compare in the common case
-  p.i_grid_old = p.i_grid;
   const bool fwd = p.x > p.x_old;
   const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
-  const bool ev_shock = p.x_old < 0 && p.x >= 0;
-  // downstream_test (particle_loop.jl:595-637) can only end the particle beyond x_dt (see refresh_dtest)
-  const bool ev_dt = p.x > p.x_dt;
-  const bool ev_prp = p.x >= h.x_grid_stop &&
-                      (p.x_old < h.x_grid_stop || (p.x_old < p.prp && p.x >= p.prp) || aa < 1);
-  if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
-  p.i_return = 2;                                             // prob_return's default (prob_return.jl:48)
-  const bool ev_other = ev_tcut | ev_reflect | ev_shock | ev_dt | ev_prp;
-  bool ev_flux = (!same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0) && ev_other;
-
-  // ================= plain zone crossing: into the neighbouring zone, nothing else going on =================
-  if (MCS_UNLIKELY(!same_zone && !ev_other)) {
-    const int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
-    // all_flux!'s search (all_flux.jl:68-72) stops at the neighbour iff its far edge is beyond x
-    const bool adjacent = fwd ? (cand + 1 < h.n_grid + 2 && S_x[cand + 1] > p.x) : (cand >= 0 && S_x[cand] <= p.x);
-    if (adjacent) {
-      p.i_grid = cand;
-      push_record(p, ig3);
-    } else {
-      ev_flux = true;      // several zones in one step, or off the grid: the search loop of the post block
-    }
-  } else if (same_zone && !ev_other && (p.i_grid <= h.i_grid_feb || h.n_xspec != 0)) {
-    ev_flux = true;
+  // the next threshold above x_old whose upward crossing means work: end of the grid, the PRP
+  // (prob_return.jl:73,89) or the downstream_test exit (x_dt, see refresh_dtest)
+  const double x_up = p.x_old < h.x_grid_stop ? h.x_grid_stop : (p.x_old < p.prp ? p.prp : p.x_dt);
+  const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);   // fine/coarse switch due
+  ev_cross = !same_zone;
+  bool ev = (p.x >= x_up) | ev_xn;
+  if (h.odd_cfg) {   // wave-uniform: configurations with more per-pass conditions
+    if (a->P.feb_downstream > 0) ev |= p.x > a->P.feb_downstream;
+    if (h.dont_DSA || a->inj_frac < 1) ev |= p.x <= 0 && p.x_old > 0 && !p.inj;
+    if (a->aa < 1) ev |= p.x >= h.x_grid_stop;
+    if (a->tb.n_xspec != 0) ev = true;
   }
+  return ev;
+}
 
-  // ================= post: rare work after the move =================
-  PROF_LANES(16, ev_other | ev_flux);
-  PROF_LANES(22, ev_flux); PROF_LANES(23, ev_dt); PROF_LANES(24, ev_prp); PROF_LANES(25, ev_tcut);
-  if (MCS_UNLIKELY(ev_other | ev_flux)) {
-    PROF_ADD(15, 1);
-    [[maybe_unused]] const unsigned long long pc0 = PROF_T();
-    if (ev_tcut) {
-      tcut_track(a, p.tcut, p.weight, p.ptot_pf);
-      p.tcut += 1;
-      p.tcut_next = p.tcut <= h.n_tcuts ? S_tc[p.tcut - 1] : __builtin_inf();
+// Everything the last move triggered (the tail of Code Block 2 and Code Block 3's all_flux /
+// downstream_test / prob_return part, particle_loop.jl:352-358, 409-499).  Returns the end code or -1.
+__device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, double phi_old) {
+  const double aa = a->aa;
+  const int ig3 = p.ig3;
+  const int i_grid_before = p.i_grid;
+  p.i_grid_old = p.i_grid;
+  // time cut (cuts.jl:149-162; the clock has already run, weight and ptot_pf are those of the pass)
+  if (h.do_tcuts && p.downstream && !(p.tcut > a->tb.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
+    tcut_track(a, p.tcut, p.weight, p.ptot_pf);
+    p.tcut += 1;
+  }
+  const bool ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || a->inj_frac < 1);
+  const bool ev_shock = p.x_old < 0 && p.x >= 0;
+  if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
+  if (ev_reflect) {
+    // the retry loop of no_DSA_loop (particle_loop.jl:555-568); its first pass was the move
+    const double m = aa * MP_;
+    const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
+    while (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || a->inj_frac < 1)) {
+      if (h.dont_DSA || (rng.rand() > a->inj_frac)) {
+        if (p.pb_pf < 0) p.pb_pf = -p.pb_pf; else p.phi = rng.rand() * TWOPI_;
+      } else break;
+      p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
+      const double x_move = p.pb_pf * p.t_step / (p.gam_pf * m);
+      double gyr = 0.0;
+      if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+      const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
+      p.x = p.x_old + dx;
     }
-    if (ev_reflect) {
-      // the retry loop of no_DSA_loop (particle_loop.jl:555-568); its first pass is the move above
-      const double m = aa * MP_;
-      while (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1)) {
-        if (h.dont_DSA || (rng.rand() > h.inj_frac)) {
-          if (p.pb_pf < 0) p.pb_pf = -p.pb_pf; else p.phi = rng.rand() * TWOPI_;
-        } else break;
-        p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
-        const double x_move = p.pb_pf * p.t_step / (p.gam_pf * m);
-        double gyr = 0.0;
-        if (bsin != 0.0) gyr = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
-        const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
-        p.x = p.x_old + dx;
-      }
+  }
+  if (ev_shock || ev_reflect) {
+    if (p.x_old < 0 && p.x >= 0) {          // particle_loop.jl:412-429
+      p.downstream = true;
+      const double L_diff = a->P.eta_mfp / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * a->P.u2);
+      p.prp = p.prp > L_diff ? p.prp : L_diff;
+      p.flags |= F_RS;                       // F_SAVE depends on `downstream`
     }
-    if (ev_shock || ev_reflect) {
-      if (p.x_old < 0 && p.x >= 0) {          // particle_loop.jl:412-429
-        p.downstream = true;
-        const double L_diff = h.eta / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * h.u2);
-        p.prp = p.prp > L_diff ? p.prp : L_diff;
-      }
-      if (p.downstream && p.x < 0) p.inj = true;
-    }
-    if (ev_flux || ev_reflect) {
-      // all_flux! (all_flux.jl:45-82): zone search; tallies only when something was crossed
-      const int ne = h.n_grid + 2;
+    if (p.downstream && p.x < 0) p.inj = true;
+  }
+  {
+    // all_flux! (all_flux.jl:45-82): zone search; a tally record only when something was crossed
+    const bool fwd = p.x > p.x_old;
+    const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
+    if (!same_zone || p.i_grid <= a->P.i_grid_feb || a->tb.n_xspec != 0 || ev_reflect) {
+      const int ne = a->P.n_grid + 2;
       int found = -1;
-      if (p.x > p.x_old) {
+      if (fwd) {
         for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { found = j - 1; break; }
       } else {
         for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { found = j; break; }
       }
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
-      if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) {
-        push_record(p, ig3);
-        PROF_ADD(19, 1); PROF_LANES(18, true);
-      }
+      if (!(p.i_grid == p.i_grid_old && p.i_grid > a->P.i_grid_feb && a->tb.n_xspec == 0)) push_record(p, ig3);
     }
-    // downstream_test (particle_loop.jl:595-637) and prob_return; after a reflection or a
-    // shock crossing x and prp may have changed, so the tests are redone from scratch
-    bool do_prob_ret = true;
-    if (h.feb_down > 0 && p.x > h.feb_down) {
-      p.i_return = 0; do_prob_ret = false;
-    } else if (p.x > 1.1 * p.prp) {
-      const double m = aa * MP_;
-      double v_fac;
-      if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
-        const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
-        v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
-      } else {
-        v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
-      }
-      const double L_diff = h.eta / 3 * v_fac;
-      if (p.x > 6.91 * L_diff) { p.i_return = 0; do_prob_ret = false; }
-    }
-    bool lose_pt = false;
-    if (do_prob_ret) prob_return_events(a, s, h, rng, p, lose_pt);
-
-    if (p.i_return == 0) {
-      double vel = p.ptot_pf / h.m;
-      if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
-      sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
-      sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
-      return lose_pt ? 4 : 1;
-    }
-    refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
-    PROF_ADD(17, PROF_T() - pc0);
   }
+  // downstream_test (particle_loop.jl:595-637) and prob_return, from scratch
+  int i_return = 2;                              // prob_return's default (prob_return.jl:48)
+  bool do_prob_ret = true;
+  if (a->P.feb_downstream > 0 && p.x > a->P.feb_downstream) {
+    i_return = 0; do_prob_ret = false;
+  } else if (p.x > 1.1 * p.prp) {
+    const double m = aa * MP_;
+    double v_fac;
+    if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
+      const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
+      v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * a->P.u2);
+    } else {
+      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * a->P.u2);
+    }
+    const double L_diff = a->P.eta_mfp / 3 * v_fac;
+    if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; }
+  }
+  bool lose_pt = false;
+  if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt);
+  if (i_return == 0) {
+    double vel = p.ptot_pf / h.m;
+    if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
+    sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
+    sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
+    return lose_pt ? 4 : 1;
+  }
+  // the particle goes on: what the next pass has to know
+  int f = p.flags | F_CHECK;
+  if (i_return == 1) f |= F_B1;
+  if (p.i_grid != i_grid_before) f |= F_CROSSED; else f &= ~F_CROSSED;
+  if (p.i_grid != p.ig3) f |= F_ZONE;
+  f = p.i_grid <= a->P.i_grid_feb ? (f | F_NEARFEB) : (f & ~F_NEARFEB);
+  p.flags = f;
+  refresh_time(a, h, p);
+  refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
   return -1;
+}
+
+// t_step, 2pi/xn_per and 1/(gamma m): particle_loop.jl:400,529,531
+__device__ __forceinline__ void refresh_move(CK* a, const Hot& h, Pt& p) {
+  p.dphi = TWOPI_ / p.xn_per;
+  p.t_step = p.gyro_period / p.xn_per;
+  p.rg_val = rcp_refined(p.gam_pf * (a->aa * MP_));
+  p.flags &= ~F_RM;
+}
+
+// Everything before the next scatter (head of the loop body and of Code Block 3,
+// particle_loop.jl:154-326, 361-385).  `t_clock` is the time step of the previous move, which the
+// clock of this pass still uses (particle_loop.jl:350 precedes :400).  Returns the end code or -1.
+__device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock) {
+  const double aa = a->aa;
+  if (p.helix >= MCS_HELIX_CAP) {            // the pass about to start would be number cap+1: quirk Q5
+    p.helix += 1;
+    cnt(a, MCS_IC_HELIX_CAP);
+    return 1;
+  }
+  int f = p.flags;
+  if ((f & F_ZONE) || h.custom_epsB || (h.etf && (f & F_CROSSED))) {
+    // head of Code Block 3 (particle_loop.jl:186-246)
+    const int ig = p.i_grid, io = p.ig3;
+    const bool etf_ev = h.etf && (f & F_CROSSED) && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
+    p.ig3 = ig;
+    double gd;
+    if (h.custom_epsB && p.x > h.x_grid_stop) {
+      const double bmag = S_bt[a->P.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+      gd = 1 / (a->zzq * bmag);
+    } else {
+      gd = S_gd[ig];                         // == 1/(zz*btot[ig]), tabulated per zone
+    }
+    if (gd != p.gyro_denom) { p.gyro_denom = gd; f |= F_RS | F_RM; }
+    if (ig != io && S_ux[ig] != S_ux[io]) {  // same u_x => no frame transform (particle_loop.jl:214)
+      const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
+      p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+      p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+      f |= F_RS | F_RM;
+    }
+    if (etf_ev) {
+      Mom r; r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
+      r = do_energy_transfer(a, p.i_grid, p.i_grid_old, p.weight, r);
+      p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam;
+      f |= F_RS | F_RM;
+    }
+  }
+  f &= ~(F_ZONE | F_CROSSED | F_CHECK);
+  p.flags = f;
+  // exit tests of Code Block 3 (particle_loop.jl:251-300), after the transforms
+  const int ig = p.ig3;
+  if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.helix += 1; return 1; }
+  if (p.ptot_pf > a->pmax_cutoff) {          // rare (only near p_max)
+    double ptot_sk, px, py, pz, gam_sk;
+    transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
+    if (ptot_sk > a->pmax_cutoff) { p.helix += 1; return 2; }
+  }
+  if (p.inj && p.x < a->P.feb_upstream) { p.helix += 1; return 2; }
+  if (a->P.age_max > 0 && p.acctime > a->P.age_max) { p.helix += 1; return 3; }
+  if (h.rad_losses && aa < 1) {
+    double bmag = S_bt[ig];
+    if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[a->P.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+    const double ptot_old = p.ptot_pf;
+    const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
+    p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, t_clock);
+    if (p.ptot_pf <= 0) {
+      p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
+      p.helix += 1;
+      return 4;
+    }
+    p.gam_pf = mcsm::hypot1(p.ptot_pf / a->mc);
+    p.pb_pf *= p.ptot_pf / ptot_old;
+    p.p_perp *= p.ptot_pf / ptot_old;
+    p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+    p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+    p.flags |= F_RS | F_RM;
+  }
+  if (p.flags & F_RS) {
+    if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, a->P.eta_mfp);   // with the OLD xn_per, as the reference
+    refresh_dtest(a, h, p);
+    int g = p.flags & ~(F_RS | F_NEARP | F_SAVE);
+    if (p.ptot_pf > a->pmax_cutoff) g |= F_NEARP;
+    if (p.downstream && p.ptot_pf > a->pcut) g |= F_SAVE;
+    p.flags = g;
+  }
+  if (p.flags & F_SAVE) {
+    // saved for the next pcut (particle_loop.jl:361-380): scatter, clock, time cut -- no move
+    p.helix += 1;
+    if (!h.dont_scatter) scattering(rng, p, kc);
+    p.acctime += t_clock * S_gef[ig];        // F_SAVE implies downstream
+    p.n_ovr += (unsigned)p.ovr_inc;
+    if (h.do_tcuts && !(p.tcut > a->tb.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
+      tcut_track(a, p.tcut, p.weight, p.ptot_pf);
+      p.tcut += 1;
+    }
+    return 0;
+  }
+  // fine / coarse step (particle_loop.jl:382-385); decided before the scatter here, after it in the
+  // reference -- the scatter touches neither x nor gyro_rad_tot.  cos_max keeps the old xn_per for
+  // the coming scatter and is refreshed for the one after (F_RS), exactly as in the reference.
+  const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : a->P.xn_per_fine;
+  if (xn != p.xn_per) { p.xn_per = xn; p.flags |= F_RS | F_RM; }
+  if (p.flags & F_RM) refresh_move(a, h, p);
+  return -1;
+}
+
+// A Code Block 1 pass (particle_loop.jl:167-177 then Code Block 2): no Code Block 3, so no scatter,
+// no clock, no exit test.  Done entirely in the rare block so that the common pass has no such case.
+__device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& phi_old, int& end) {
+  if (p.helix >= MCS_HELIX_CAP) { p.helix += 1; cnt(a, MCS_IC_HELIX_CAP); end = 1; return false; }
+  p.helix += 1;
+  p.p_perp = perpendicular_momentum(a, p.ptot_pf, p.pb_pf);
+  p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+  p.flags &= ~(F_B1 | F_CROSSED);
+  if (p.flags & F_RM) refresh_move(a, h, p);
+  bool cross;
+  const bool other = move_and_detect(a, h, p, phi_old, cross);
+  return other | cross;
+}
+
+// The most frequent event by far: the move ended in the neighbouring zone and nothing else is
+// going on (no flag set, no other event, not the shock, same flow speed and field on both sides, not
+// the FEB zone).  What slow_post + slow_pre would do then is: inj update (particle_loop.jl:433-435),
+// the all_flux record (all_flux.jl:68-82, 130-137) and the zone reload of the next Code Block 3
+// (particle_loop.jl:186-204); every exit test is known to be false.  Returns false if it is not that case.
+__device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
+  const bool fwd = p.x > p.x_old;
+  const int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
+  const bool adjacent = fwd ? (cand + 1 < a->P.n_grid + 2 && S_x[cand + 1] > p.x) : (cand >= 0 && S_x[cand] <= p.x);
+  if (!adjacent) return false;
+  if (p.x_old < 0 && p.x >= 0) return false;                           // shock crossing
+  if (cand <= a->P.i_grid_feb) return false;
+  if (S_ux[cand] != S_ux[p.ig3] || S_gd[cand] != p.gyro_denom) return false;
+  if (p.downstream && p.x < 0) p.inj = true;
+  p.i_grid_old = p.i_grid;
+  p.i_grid = cand;
+  push_record(p, p.ig3);
+  p.ig3 = cand;
+  return true;
 }
 
 }  // namespace
@@ -1092,16 +1142,18 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   // neither re-load them from the constant buffer inside the loop (s_load + s_waitcnt) nor
   // spill them as SGPRs.
   Hot h;
-  h.aa = vconst(a->aa); h.m = vconst(a->m); h.mc = vconst(a->mc); h.zzq = vconst(a->zzq); h.pcut = vconst(a->pcut);
-  h.pmax_cutoff = vconst(a->pmax_cutoff);
-  h.feb_up = vconst(a->P.feb_upstream); h.feb_down = vconst(a->P.feb_downstream); h.age_max = vconst(a->P.age_max);
-  h.x_grid_stop = vconst(a->P.x_grid_stop); h.u2 = vconst(a->P.u2); h.eta = vconst(a->P.eta_mfp);
-  h.xn_fine = vconst(a->P.xn_per_fine); h.xn_coarse = vconst(a->P.xn_per_coarse); h.inj_frac = vconst(a->inj_frac);
-  h.n_grid = vconsti(ng); h.i_grid_feb = vconsti(a->P.i_grid_feb); h.n_tcuts = vconsti(ntc); h.n_xspec = vconsti(a->tb.n_xspec);
+  h.m = vconst(a->m); h.x_grid_stop = vconst(a->P.x_grid_stop); h.xn_coarse = vconst(a->P.xn_per_coarse);
   // uniform flags stay scalar (s_cbranch): whole code regions are skipped for free
   h.custom_epsB = a->P.use_custom_epsB != 0; h.etf = a->P.energy_transfer_frac > 0;
   h.dont_scatter = a->P.dont_scatter != 0; h.rad_losses = a->P.do_rad_losses != 0;
   h.do_tcuts = a->P.do_tcuts != 0; h.dont_DSA = a->P.dont_DSA != 0;
+  {
+    int ob = 0;
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) ob |= S_bsin[i] != 0.0;
+    h.oblique = __syncthreads_or(ob) != 0;
+  }
+  h.every_pass = h.custom_epsB || (h.rad_losses && a->aa < 1) || h.dont_scatter;
+  h.odd_cfg = a->P.feb_downstream > 0 || h.dont_DSA || a->inj_frac < 1 || a->aa < 1 || a->tb.n_xspec != 0;
 
   // the 25 polynomial coefficients of the per-step sincos + asin, resident in VGPRs
   mcsm::HotCoef kc;
@@ -1116,7 +1168,17 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
 
   Pt p;
   Rng rng;
+  // idle lanes run the common pass too (on whatever state they hold): give them valid table indices
+  p.weight = 0; p.ptot_pf = 1; p.pb_pf = 0; p.p_perp = 1; p.gam_pf = 1; p.x = 0; p.x_old = 0; p.phi = 0; p.prp = 0; p.acctime = 0;
+  p.xn_per = 1; p.dphi = 0; p.gyro_denom = 0; p.gyro_rad = 0; p.gyro_rad_tot = 0; p.gyro_period = 0; p.t_step = 0;
+  p.rp_val = 1; p.cm_val = 1; p.rg_val = 1; p.x_dt = 0; p.t_ev = 0; p.flags = 0; p.ovr_inc = 0; p.n_ovr = 0u;
+  p.i_grid = 0; p.i_grid_old = 0; p.ig3 = 0; p.helix = 0; p.tcut = 1; p.n_retro = 0; p.downstream = false; p.inj = false;
+  rng.init(0ull);
   bool active = false, exhausted = false;
+  bool ev = false;        // the last move of this lane needs slow_post
+  bool ev_x = false;      // the last move of this lane left its zone
+  bool moved = false;     // this lane's particle has made a move since it was loaded
+  double phi_prev = 0.0;  // phase before the last move (the no-DSA retry loop needs it)
   long long k = -1;
   unsigned long long c_helix = 0, c_retro = 0, c_draws = 0;
   const unsigned lane = __lane_id();
@@ -1126,12 +1188,9 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.pushed = false;
   for (;;) {
-    [[maybe_unused]] const unsigned long long pt0 = PROF_T();
     ev_pending += (unsigned)__popcll(__ballot(p.pushed));
     p.pushed = false;
     if (MCS_UNLIKELY(ev_pending >= 64u)) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
-    [[maybe_unused]] const unsigned long long pt1 = PROF_T();
-    PROF_ADD(2, pt1 - pt0);
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
     if (MCS_UNLIKELY(idle != 0ull && !exhausted)) {
@@ -1148,29 +1207,43 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
         if (idx < n) {
           k = (long long)idx;
           load_particle(a, s, h, k, p, rng);
-          active = true;
+          active = true; ev = false; ev_x = false; moved = false;
         }
       }
       PROF_ADD(5, 1); PROF_ADD(6, nidle);
     }
-    [[maybe_unused]] const unsigned long long pt2 = PROF_T();
-    PROF_ADD(4, pt2 - pt1);
     {
-      const int na__ = __popcll(__ballot(active));
+      [[maybe_unused]] const int na__ = __popcll(__ballot(active));
       PROF_ADD(0, 1); PROF_ADD(8, na__);
-      if (na__ <= 8) PROF_ADD(21, 1);
     }
     if (MCS_UNLIKELY(__ballot(active) == 0ull)) {
       if (exhausted) break;
       continue;
     }
-    int end = -1;
-    if (active) end = helix_step(a, s, h, kc, rng, p);
-    [[maybe_unused]] const unsigned long long pt3 = PROF_T();
-    PROF_ADD(7, pt3 - pt2);
-    PROF_LANES(11, active && end >= 0);
-    if (active) {
-      if (MCS_UNLIKELY(end >= 0)) {
+    double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
+    // ---- the one rare region (see the comment above move_and_detect)
+    const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
+    const bool unusual = p.flags != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass;
+    PROF_LANES(13, active && (post_pending || unusual));
+    if (MCS_UNLIKELY(active && (post_pending || unusual))) {
+      PROF_ADD(12, 1);
+      int end = -1;
+      bool full = unusual || ev || h.etf || h.custom_epsB;
+      if (!full) full = !plain_crossing(a, h, p);
+      PROF_LANES(16, full);
+      if (full) {
+        bool pend = post_pending;
+        for (;;) {
+          if (pend) { end = slow_post(a, s, h, rng, p, phi_prev); if (end >= 0) break; }
+          if (!(p.flags & F_B1)) break;
+          pend = block1_step(a, h, p, phi_prev, end);
+          if (end >= 0) break;
+          pend = pend || (p.flags & F_NEARFEB) != 0;
+          t_clock = p.t_step;
+        }
+        if (end < 0) end = slow_pre(a, s, h, kc, rng, p, t_clock);
+      }
+      if (end >= 0) {
         PROF_ADD(10, 1);
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
         c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
@@ -1191,12 +1264,21 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
           a->f_reason[k] = end; a->f_helix[k] = p.helix; a->f_retro[k] = p.n_retro; a->f_ptot[k] = p.ptot_pf; a->f_x[k] = p.x;
         }
         active = false;
+        p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
       }
     }
-    [[maybe_unused]] const unsigned long long pt4 = PROF_T();
-    PROF_ADD(9, pt4 - pt3);
-    PROF_ADD(1, pt4 - pt0);
-    PROF_ADD(20, PROF_T() - pt4);   // cost of one timer read
+    // ---- the common pass, for every lane (idle lanes compute on stale state; nothing is stored)
+    p.helix += 1;
+    if (!h.dont_scatter) scattering(rng, p, kc);
+    {
+      const bool ds = p.downstream;
+      const double acc_new = p.acctime + t_clock * S_gef[p.ig3];
+      p.acctime = ds ? acc_new : p.acctime;
+      p.n_ovr += (unsigned)p.ovr_inc;
+      const bool ev_time = ds && p.acctime >= p.t_ev;
+      ev = move_and_detect(a, h, p, phi_prev, ev_x) | ev_time;
+    }
+    moved = true;
   }
 
   // ---- flush per-lane counters (wave reduce) and the LDS staging
