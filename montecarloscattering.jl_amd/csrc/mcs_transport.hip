@@ -1071,18 +1071,22 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
   return other | cross;
 }
 
-// The most frequent event by far: the move ended in the neighbouring zone and nothing else is
+// The most frequent event by far: the move ended in another zone and nothing else is
 // going on (no flag set, no other event, not the shock, same flow speed and field on both sides, not
 // the FEB zone).  What slow_post + slow_pre would do then is: inj update (particle_loop.jl:433-435),
 // the all_flux record (all_flux.jl:68-82, 130-137) and the zone reload of the next Code Block 3
 // (particle_loop.jl:186-204); every exit test is known to be false.  Returns false if it is not that case.
 __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
-  const bool fwd = p.x > p.x_old;
-  const int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
-  const bool adjacent = fwd ? (cand + 1 < a->P.n_grid + 2 && S_x[cand + 1] > p.x) : (cand >= 0 && S_x[cand] <= p.x);
-  if (!adjacent) return false;
   if (p.x_old < 0 && p.x >= 0) return false;                           // shock crossing
-  if (cand <= a->P.i_grid_feb) return false;
+  // all_flux!'s zone search (all_flux.jl:68-72); one step can cross several of the thin zones
+  const int ne = a->P.n_grid + 2;
+  int cand = -1;
+  if (p.x > p.x_old) {
+    for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { cand = j - 1; break; }
+  } else {
+    for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
+  }
+  if (cand < 0 || cand <= a->P.i_grid_feb) return false;
   if (S_ux[cand] != S_ux[p.ig3] || S_gd[cand] != p.gyro_denom) return false;
   if (p.downstream && p.x < 0) p.inj = true;
   p.i_grid_old = p.i_grid;
@@ -1231,6 +1235,19 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
       bool full = unusual || ev || h.etf || h.custom_epsB;
       if (!full) full = !plain_crossing(a, h, p);
       PROF_LANES(16, full);
+#ifdef MCS_PROF
+      {
+        const double xup__ = p.x_old < h.x_grid_stop ? h.x_grid_stop : (p.x_old < p.prp ? p.prp : p.x_dt);
+        PROF_LANES(22, moved && ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse)));
+        PROF_LANES(23, moved && p.x >= xup__);
+        PROF_LANES(24, moved && p.downstream && p.acctime >= p.t_ev);
+        PROF_LANES(25, (p.flags & (F_RS | F_RM)) != 0);
+        PROF_LANES(26, full && !unusual && !ev);
+        PROF_LANES(27, (p.flags & F_NEARFEB) != 0);
+        PROF_LANES(28, (p.flags & F_SAVE) != 0);
+        PROF_LANES(29, !moved);
+      }
+#endif
       if (full) {
         bool pend = post_pending;
         for (;;) {

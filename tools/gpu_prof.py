@@ -36,10 +36,9 @@ for ip in range(1, NPC + 1):
         tot = cyc(1)
         print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3):.3e}/s  (timer read = {tr:.0f} cyc)")
         print(f"   wave passes {passes:.3e}, active lanes/pass {P[8]/passes:.1f}, passes with <=8 active {100*P[21]/passes:.1f} %, cycles/pass {tot/passes:.0f}")
-        print(f"   share of wave-cycles: drain {100*cyc(2)/tot:.1f} %  refill {100*cyc(4)/tot:.1f} %  step {100*cyc(7)/tot:.1f} %  finish {100*cyc(9)/tot:.1f} %")
-        print(f"   post block: {P[17]/max(P[15],1)-tr:.0f} cycles per entry (timer cost removed), {100*(P[17]-tr*P[15])/tot:.1f} % of wave-cycles")
-        print(f"   drains/pass {P[3]/passes:.4f}  refills/pass {P[5]/passes:.4f} ({P[6]/max(P[5],1):.1f} lanes each)  finish passes/pass {P[10]/passes:.4f} ({P[11]/max(P[10],1):.1f} lanes each)")
-        print(f"   phase A entered {100*P[12]/passes:.1f} % of passes ({P[13]/max(P[12],1):.1f} lanes each);  phase C entered {100*P[15]/passes:.1f} % ({P[16]/max(P[15],1):.1f} lanes each)")
-        print(f"   C causes per pass (lanes): flux {P[22]/passes:.2f} dtest {P[23]/passes:.2f} prp {P[24]/passes:.2f} tcut {P[25]/passes:.2f}; pushes/pass {P[19]/passes:.3f} ({P[18]/max(P[19],1):.1f} lanes each)", flush=True)
+        print(f"   rare region entered in {100*P[12]/passes:.1f} % of passes ({P[13]/max(P[12],1):.1f} lanes each); full path for {P[16]/max(P[12],1):.2f} lanes per entry")
+        e = max(P[12], 1)
+        print(f"   lanes per entry with: xn switch due {P[22]/e:.2f}, x>=x_up {P[23]/e:.2f}, time event {P[24]/e:.2f}, refresh flags {P[25]/e:.2f}, crossing not plain {P[26]/e:.2f}, near FEB {P[27]/e:.2f}, to be saved {P[28]/e:.2f}, new particle {P[29]/e:.2f}")
+        print(f"   drains/pass {P[3]/passes:.4f}  refills/pass {P[5]/passes:.4f} ({P[6]/max(P[5],1):.1f} lanes each)  particles ended/pass {P[10]/passes:.4f}", flush=True)
     if ns == 0: break
     hb.new_pcut(max(N // ns, 1))
