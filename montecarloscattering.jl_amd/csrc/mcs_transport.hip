@@ -578,14 +578,20 @@ __device__ __forceinline__ int vconsti(int x) { asm volatile("" : "+v"(x)); retu
 
 // hot-loop constants, fetched once per wave and parked in VGPRs (see the kernel prologue)
 struct Hot {
-  double m, x_grid_stop, xn_coarse;     // used by every pass: parked in VGPRs
+  double m, x_grid_stop, xn_coarse;     // used by every pass: parked in VGPRs (vconst)
+  // Needed by rare code only: loaded once per wave into SCALAR registers behind an opaque move (sconst).
+  // The allocator keeps them in SGPRs or in lanes of a spill VGPR (v_readlane at the rare use) -- a few
+  // cycles either way, where re-loading from the constant buffer is an s_load + wait of ~200 cycles per
+  // use (measured: it tripled the cost of the rare region).
+  double u2, eta, zzq, mc, feb_down, pcut, pmax_cutoff, feb_up, age_max, inj_frac, xn_fine, aa;
+  int n_grid, i_grid_feb, n_tcuts, n_xspec;
   bool custom_epsB, etf, dont_scatter, rad_losses, do_tcuts, dont_DSA;   // wave-uniform flags (scalar branches)
   bool oblique;     // some zone has b_sin != 0 (the gyro term of the move is not identically zero)
   bool odd_cfg;     // downstream FEB, no-DSA / injection probability, electrons or x_spec detectors: extra per-pass tests
   bool every_pass;  // custom eps_B, radiative losses of electrons, no-scatter runs: slow_pre has work in every pass
 };
-// Everything else is read from the launch constants (constant address space: s_load) where the rare
-// code needs it, instead of occupying registers for the whole loop.
+__device__ __forceinline__ double sconst(double x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ int sconsti(int x) { asm volatile("" : "+s"(x)); return x; }
 
 
 // src/particle_loop.jl:652-723
@@ -667,21 +673,21 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
 
 // tcuts[tcut-1] or +inf past the last cut (D4)
 __device__ __forceinline__ double tcut_next_of(CK* a, const Hot& h, int tcut) {
-  return (h.do_tcuts && tcut <= a->tb.n_tcuts) ? S_tc[tcut - 1] : __builtin_inf();
+  return (h.do_tcuts && tcut <= h.n_tcuts) ? S_tc[tcut - 1] : __builtin_inf();
 }
 // The clock compares acctime with ONE number: the earlier of the next time cut and age_max.
 __device__ __forceinline__ void refresh_time(CK* a, const Hot& h, Pt& p) {
   double t = tcut_next_of(a, h, p.tcut);
-  if (a->P.age_max > 0 && a->P.age_max < t) t = a->P.age_max;
+  if (h.age_max > 0 && h.age_max < t) t = h.age_max;
   p.t_ev = t;
-  p.ovr_inc = (h.do_tcuts && p.downstream && p.tcut > a->tb.n_tcuts) ? 1 : 0;
+  p.ovr_inc = (h.do_tcuts && p.downstream && p.tcut > h.n_tcuts) ? 1 : 0;
 }
 
 // src/prob_return.jl:36-173, entered only when it has something to do (the caller has
 // already set i_return = 2 and filtered the no-op cases).
 __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt) {
   const auto& P = a->P;
-  const double aa = a->aa, u2 = a->P.u2, eta = a->P.eta_mfp, x_grid_stop = h.x_grid_stop;
+  const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
   if (p.x < x_grid_stop) {
   } else if (p.x_old < x_grid_stop && x_grid_stop <= p.x) {
     double gyro_tmp;
@@ -746,7 +752,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
   rng.init(key);
 
-  p.gam_pf = mcsm::hypot1(p.ptot_pf / a->mc);
+  p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
   p.gyro_denom = S_gd[p.i_grid];
   if (h.custom_epsB && p.x > h.x_grid_stop) p.gyro_denom *= __builtin_sqrt(p.x / h.x_grid_stop);
   p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
@@ -757,7 +763,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
-  p.flags = F_RS | F_RM | (p.i_grid <= a->P.i_grid_feb ? F_NEARFEB : 0);
+  p.flags = F_RS | F_RM | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0);
   p.n_ovr = 0u;
   refresh_time(a, h, p);
   p.pushed = false;
@@ -782,18 +788,18 @@ __device__ __forceinline__ void push_record(Pt& p, int ig3) {
 // (x > 1.1 prp  and  x > 6.91 L_diff).  x_dt is that threshold, min(feb, max(1.1 prp, 6.91 L_diff)): a
 // function of (prp, ptot_pf, gam_pf, gyro_rad_tot, gyro_denom), refreshed whenever one of them changed.
 __device__ __forceinline__ void refresh_dtest(CK* a, const Hot& h, Pt& p) {
-  const double aa = a->aa, m = aa * MP_;
+  const double aa = h.aa, m = aa * MP_;
   double v_fac;
   if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
     const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
-    v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * a->P.u2);
+    v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
   } else {
-    v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * a->P.u2);
+    v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
   }
-  const double L_diff = a->P.eta_mfp / 3 * v_fac;
+  const double L_diff = h.eta / 3 * v_fac;
   const double t1 = 1.1 * p.prp, t2 = 6.91 * L_diff;
   double t = t1 > t2 ? t1 : t2;
-  if (a->P.feb_downstream > 0 && a->P.feb_downstream < t) t = a->P.feb_downstream;
+  if (h.feb_down > 0 && h.feb_down < t) t = h.feb_down;
   p.x_dt = t;
 }
 
@@ -849,10 +855,10 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
   ev_cross = !same_zone;
   bool ev = (p.x >= x_up) | ev_xn;
   if (h.odd_cfg) {   // wave-uniform: configurations with more per-pass conditions
-    if (a->P.feb_downstream > 0) ev |= p.x > a->P.feb_downstream;
-    if (h.dont_DSA || a->inj_frac < 1) ev |= p.x <= 0 && p.x_old > 0 && !p.inj;
-    if (a->aa < 1) ev |= p.x >= h.x_grid_stop;
-    if (a->tb.n_xspec != 0) ev = true;
+    if (h.feb_down > 0) ev |= p.x > h.feb_down;
+    if (h.dont_DSA || h.inj_frac < 1) ev |= p.x <= 0 && p.x_old > 0 && !p.inj;
+    if (h.aa < 1) ev |= p.x >= h.x_grid_stop;
+    if (h.n_xspec != 0) ev = true;
   }
   return ev;
 }
@@ -860,24 +866,24 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
 // Everything the last move triggered (the tail of Code Block 2 and Code Block 3's all_flux /
 // downstream_test / prob_return part, particle_loop.jl:352-358, 409-499).  Returns the end code or -1.
 __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, double phi_old) {
-  const double aa = a->aa;
+  const double aa = h.aa;
   const int ig3 = p.ig3;
   const int i_grid_before = p.i_grid;
   p.i_grid_old = p.i_grid;
   // time cut (cuts.jl:149-162; the clock has already run, weight and ptot_pf are those of the pass)
-  if (h.do_tcuts && p.downstream && !(p.tcut > a->tb.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
+  if (h.do_tcuts && p.downstream && !(p.tcut > h.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
     tcut_track(a, p.tcut, p.weight, p.ptot_pf);
     p.tcut += 1;
   }
-  const bool ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || a->inj_frac < 1);
+  const bool ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1);
   const bool ev_shock = p.x_old < 0 && p.x >= 0;
   if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
   if (ev_reflect) {
     // the retry loop of no_DSA_loop (particle_loop.jl:555-568); its first pass was the move
     const double m = aa * MP_;
     const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], bsin = S_bsin[ig3], ux = S_ux[ig3];
-    while (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || a->inj_frac < 1)) {
-      if (h.dont_DSA || (rng.rand() > a->inj_frac)) {
+    while (p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1)) {
+      if (h.dont_DSA || (rng.rand() > h.inj_frac)) {
         if (p.pb_pf < 0) p.pb_pf = -p.pb_pf; else p.phi = rng.rand() * TWOPI_;
       } else break;
       p.phi = mcsm::mod2pi(p.phi + TWOPI_ / p.xn_per);
@@ -891,7 +897,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
   if (ev_shock || ev_reflect) {
     if (p.x_old < 0 && p.x >= 0) {          // particle_loop.jl:412-429
       p.downstream = true;
-      const double L_diff = a->P.eta_mfp / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * a->P.u2);
+      const double L_diff = h.eta / 3 * p.gyro_rad_tot * p.ptot_pf / (h.m * p.gam_pf * h.u2);
       p.prp = p.prp > L_diff ? p.prp : L_diff;
       p.flags |= F_RS;                       // F_SAVE depends on `downstream`
     }
@@ -901,8 +907,8 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
     // all_flux! (all_flux.jl:45-82): zone search; a tally record only when something was crossed
     const bool fwd = p.x > p.x_old;
     const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
-    if (!same_zone || p.i_grid <= a->P.i_grid_feb || a->tb.n_xspec != 0 || ev_reflect) {
-      const int ne = a->P.n_grid + 2;
+    if (!same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0 || ev_reflect) {
+      const int ne = h.n_grid + 2;
       int found = -1;
       if (fwd) {
         for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { found = j - 1; break; }
@@ -911,24 +917,24 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
       }
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
-      if (!(p.i_grid == p.i_grid_old && p.i_grid > a->P.i_grid_feb && a->tb.n_xspec == 0)) push_record(p, ig3);
+      if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) push_record(p, ig3);
     }
   }
   // downstream_test (particle_loop.jl:595-637) and prob_return, from scratch
   int i_return = 2;                              // prob_return's default (prob_return.jl:48)
   bool do_prob_ret = true;
-  if (a->P.feb_downstream > 0 && p.x > a->P.feb_downstream) {
+  if (h.feb_down > 0 && p.x > h.feb_down) {
     i_return = 0; do_prob_ret = false;
   } else if (p.x > 1.1 * p.prp) {
     const double m = aa * MP_;
     double v_fac;
     if (aa < 1 && p.ptot_pf < a->P.pe_crit) {
       const double gyro_fac = a->P.pe_crit * CC_ * p.gyro_denom;
-      v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * a->P.u2);
+      v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
     } else {
-      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * a->P.u2);
+      v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
     }
-    const double L_diff = a->P.eta_mfp / 3 * v_fac;
+    const double L_diff = h.eta / 3 * v_fac;
     if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; }
   }
   bool lose_pt = false;
@@ -945,7 +951,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
   if (i_return == 1) f |= F_B1;
   if (p.i_grid != i_grid_before) f |= F_CROSSED; else f &= ~F_CROSSED;
   if (p.i_grid != p.ig3) f |= F_ZONE;
-  f = p.i_grid <= a->P.i_grid_feb ? (f | F_NEARFEB) : (f & ~F_NEARFEB);
+  f = p.i_grid <= h.i_grid_feb ? (f | F_NEARFEB) : (f & ~F_NEARFEB);
   p.flags = f;
   refresh_time(a, h, p);
   refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
@@ -956,7 +962,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
 __device__ __forceinline__ void refresh_move(CK* a, const Hot& h, Pt& p) {
   p.dphi = TWOPI_ / p.xn_per;
   p.t_step = p.gyro_period / p.xn_per;
-  p.rg_val = rcp_refined(p.gam_pf * (a->aa * MP_));
+  p.rg_val = rcp_refined(p.gam_pf * (h.aa * MP_));
   p.flags &= ~F_RM;
 }
 
@@ -964,7 +970,7 @@ __device__ __forceinline__ void refresh_move(CK* a, const Hot& h, Pt& p) {
 // particle_loop.jl:154-326, 361-385).  `t_clock` is the time step of the previous move, which the
 // clock of this pass still uses (particle_loop.jl:350 precedes :400).  Returns the end code or -1.
 __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock) {
-  const double aa = a->aa;
+  const double aa = h.aa;
   if (p.helix >= MCS_HELIX_CAP) {            // the pass about to start would be number cap+1: quirk Q5
     p.helix += 1;
     cnt(a, MCS_IC_HELIX_CAP);
@@ -978,8 +984,8 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     p.ig3 = ig;
     double gd;
     if (h.custom_epsB && p.x > h.x_grid_stop) {
-      const double bmag = S_bt[a->P.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
-      gd = 1 / (a->zzq * bmag);
+      const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+      gd = 1 / (h.zzq * bmag);
     } else {
       gd = S_gd[ig];                         // == 1/(zz*btot[ig]), tabulated per zone
     }
@@ -1003,16 +1009,16 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
   // exit tests of Code Block 3 (particle_loop.jl:251-300), after the transforms
   const int ig = p.ig3;
   if (h.dont_scatter && p.x > 10 * p.gyro_rad) { p.helix += 1; return 1; }
-  if (p.ptot_pf > a->pmax_cutoff) {          // rare (only near p_max)
+  if (p.ptot_pf > h.pmax_cutoff) {          // rare (only near p_max)
     double ptot_sk, px, py, pz, gam_sk;
     transform_p_PS(aa, p.pb_pf, p.p_perp, p.gam_pf, p.phi, S_ux[ig], S_gsf[ig], S_bcos[ig], S_bsin[ig], ptot_sk, px, py, pz, gam_sk);
-    if (ptot_sk > a->pmax_cutoff) { p.helix += 1; return 2; }
+    if (ptot_sk > h.pmax_cutoff) { p.helix += 1; return 2; }
   }
-  if (p.inj && p.x < a->P.feb_upstream) { p.helix += 1; return 2; }
-  if (a->P.age_max > 0 && p.acctime > a->P.age_max) { p.helix += 1; return 3; }
+  if (p.inj && p.x < h.feb_up) { p.helix += 1; return 2; }
+  if (h.age_max > 0 && p.acctime > h.age_max) { p.helix += 1; return 3; }
   if (h.rad_losses && aa < 1) {
     double bmag = S_bt[ig];
-    if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[a->P.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
+    if (h.custom_epsB && p.x > h.x_grid_stop) bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
     const double ptot_old = p.ptot_pf;
     const double B_CMB_loc = a->P.B_CMBz * S_gef[ig];
     p.ptot_pf = radiation_loss(bmag * bmag + B_CMB_loc * B_CMB_loc, p.ptot_pf, t_clock);
@@ -1021,7 +1027,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
       p.helix += 1;
       return 4;
     }
-    p.gam_pf = mcsm::hypot1(p.ptot_pf / a->mc);
+    p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
     p.pb_pf *= p.ptot_pf / ptot_old;
     p.p_perp *= p.ptot_pf / ptot_old;
     p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
@@ -1029,11 +1035,11 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     p.flags |= F_RS | F_RM;
   }
   if (p.flags & F_RS) {
-    if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, a->P.eta_mfp);   // with the OLD xn_per, as the reference
+    if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);   // with the OLD xn_per, as the reference
     refresh_dtest(a, h, p);
     int g = p.flags & ~(F_RS | F_NEARP | F_SAVE);
-    if (p.ptot_pf > a->pmax_cutoff) g |= F_NEARP;
-    if (p.downstream && p.ptot_pf > a->pcut) g |= F_SAVE;
+    if (p.ptot_pf > h.pmax_cutoff) g |= F_NEARP;
+    if (p.downstream && p.ptot_pf > h.pcut) g |= F_SAVE;
     p.flags = g;
   }
   if (p.flags & F_SAVE) {
@@ -1042,7 +1048,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     if (!h.dont_scatter) scattering(rng, p, kc);
     p.acctime += t_clock * S_gef[ig];        // F_SAVE implies downstream
     p.n_ovr += (unsigned)p.ovr_inc;
-    if (h.do_tcuts && !(p.tcut > a->tb.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
+    if (h.do_tcuts && !(p.tcut > h.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
       tcut_track(a, p.tcut, p.weight, p.ptot_pf);
       p.tcut += 1;
     }
@@ -1051,7 +1057,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
   // fine / coarse step (particle_loop.jl:382-385); decided before the scatter here, after it in the
   // reference -- the scatter touches neither x nor gyro_rad_tot.  cos_max keeps the old xn_per for
   // the coming scatter and is refreshed for the one after (F_RS), exactly as in the reference.
-  const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : a->P.xn_per_fine;
+  const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
   if (xn != p.xn_per) { p.xn_per = xn; p.flags |= F_RS | F_RM; }
   if (p.flags & F_RM) refresh_move(a, h, p);
   return -1;
@@ -1079,14 +1085,14 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
 __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
   if (p.x_old < 0 && p.x >= 0) return false;                           // shock crossing
   // all_flux!'s zone search (all_flux.jl:68-72); one step can cross several of the thin zones
-  const int ne = a->P.n_grid + 2;
+  const int ne = h.n_grid + 2;
   int cand = -1;
   if (p.x > p.x_old) {
     for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { cand = j - 1; break; }
   } else {
     for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
   }
-  if (cand < 0 || cand <= a->P.i_grid_feb) return false;
+  if (cand < 0 || cand <= h.i_grid_feb) return false;
   if (S_ux[cand] != S_ux[p.ig3] || S_gd[cand] != p.gyro_denom) return false;
   if (p.downstream && p.x < 0) p.inj = true;
   p.i_grid_old = p.i_grid;
@@ -1147,6 +1153,11 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   // spill them as SGPRs.
   Hot h;
   h.m = vconst(a->m); h.x_grid_stop = vconst(a->P.x_grid_stop); h.xn_coarse = vconst(a->P.xn_per_coarse);
+  h.u2 = sconst(a->P.u2); h.eta = sconst(a->P.eta_mfp); h.zzq = sconst(a->zzq); h.mc = sconst(a->mc);
+  h.feb_down = sconst(a->P.feb_downstream); h.pcut = sconst(a->pcut); h.pmax_cutoff = sconst(a->pmax_cutoff);
+  h.feb_up = sconst(a->P.feb_upstream); h.age_max = sconst(a->P.age_max); h.inj_frac = sconst(a->inj_frac);
+  h.xn_fine = sconst(a->P.xn_per_fine); h.aa = sconst(a->aa);
+  h.n_grid = sconsti(ng); h.i_grid_feb = sconsti(a->P.i_grid_feb); h.n_tcuts = sconsti(ntc); h.n_xspec = sconsti(a->tb.n_xspec);
   // uniform flags stay scalar (s_cbranch): whole code regions are skipped for free
   h.custom_epsB = a->P.use_custom_epsB != 0; h.etf = a->P.energy_transfer_frac > 0;
   h.dont_scatter = a->P.dont_scatter != 0; h.rad_losses = a->P.do_rad_losses != 0;
@@ -1156,19 +1167,17 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     for (int i = threadIdx.x; i < ne; i += blockDim.x) ob |= S_bsin[i] != 0.0;
     h.oblique = __syncthreads_or(ob) != 0;
   }
-  h.every_pass = h.custom_epsB || (h.rad_losses && a->aa < 1) || h.dont_scatter;
-  h.odd_cfg = a->P.feb_downstream > 0 || h.dont_DSA || a->inj_frac < 1 || a->aa < 1 || a->tb.n_xspec != 0;
+  h.every_pass = h.custom_epsB || (h.rad_losses && h.aa < 1) || h.dont_scatter;
+  h.odd_cfg = h.feb_down > 0 || h.dont_DSA || h.inj_frac < 1 || h.aa < 1 || h.n_xspec != 0;
 
-  // the 25 polynomial coefficients of the per-step sincos + asin, resident in VGPRs
+  // the 18 hottest polynomial coefficients of the per-step sincos + asin, resident in VGPRs
   mcsm::HotCoef kc;
   kc.S0 = vconst(MCS_SIN_0); kc.S1 = vconst(MCS_SIN_1); kc.S2 = vconst(MCS_SIN_2); kc.S3 = vconst(MCS_SIN_3);
   kc.S4 = vconst(MCS_SIN_4); kc.S5 = vconst(MCS_SIN_5);
   kc.C0 = vconst(MCS_COS_0); kc.C1 = vconst(MCS_COS_1); kc.C2 = vconst(MCS_COS_2); kc.C3 = vconst(MCS_COS_3);
   kc.C4 = vconst(MCS_COS_4); kc.C5 = vconst(MCS_COS_5);
   kc.A0 = vconst(MCS_ASIN_0); kc.A1 = vconst(MCS_ASIN_1); kc.A2 = vconst(MCS_ASIN_2); kc.A3 = vconst(MCS_ASIN_3);
-  kc.A4 = vconst(MCS_ASIN_4); kc.A5 = vconst(MCS_ASIN_5); kc.A6 = vconst(MCS_ASIN_6); kc.A7 = vconst(MCS_ASIN_7);
-  kc.A8 = vconst(MCS_ASIN_8); kc.A9 = vconst(MCS_ASIN_9); kc.A10 = vconst(MCS_ASIN_10); kc.A11 = vconst(MCS_ASIN_11);
-  kc.A12 = vconst(MCS_ASIN_12);
+  kc.A4 = vconst(MCS_ASIN_4); kc.A5 = vconst(MCS_ASIN_5);
 
   Pt p;
   Rng rng;
