@@ -50,6 +50,6 @@ struct KArgs {
 
 // zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old
-#define MCS_EV_CAP 128       // records per wave (drained 64 at a time)
+#define MCS_EV_CAP 192       // records per wave: < 64 after the drain + at most 2 per lane in one pass
 
 #endif

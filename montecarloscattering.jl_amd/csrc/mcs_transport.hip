@@ -203,7 +203,7 @@ struct Pt {
   unsigned n_ovr;                // passes counted by D4, flushed when the particle ends
   int i_grid, i_grid_old, ig3, helix, tcut, n_retro;
   bool downstream, inj;
-  bool pushed;                   // this lane pushed a tally record in the current pass
+  int npush;                     // tally records this lane pushed in the current pass (0..2)
 };
 
 // Tally atomics with the address space spelled out, so that the ISA is
@@ -766,12 +766,14 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.flags = F_RS | F_RM | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0);
   p.n_ovr = 0u;
   refresh_time(a, h, p);
-  p.pushed = false;
+  p.npush = 0;
 }
 
 // Zone-crossing tallies do not feed back into the particle: the lane pushes a record on its wave's
 // LDS stack (see S_evf) instead of tallying on the spot.  The stack cannot overflow: it is drained
-// to < 64 at the top of every pass and one pass adds at most one record per lane.
+// to < 64 at the top of every pass and one pass adds at most two records per lane -- one for the move
+// of the previous common pass and one for a Code Block 1 move (a second PRP return cannot follow
+// directly: the retro walk leaves the particle AT the PRP, and a return needs x_old < prp).
 __device__ __forceinline__ void push_record(Pt& p, int ig3) {
   const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
   const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
@@ -781,7 +783,7 @@ __device__ __forceinline__ void push_record(Pt& p, int ig3) {
   S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
   S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
   if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
-  p.pushed = true;
+  p.npush += 1;
 }
 
 // downstream_test (particle_loop.jl:595-637) ends a particle iff  x > feb_downstream (when set)  or
@@ -1084,16 +1086,29 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
 // (particle_loop.jl:186-204); every exit test is known to be false.  Returns false if it is not that case.
 __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
   if (p.x_old < 0 && p.x >= 0) return false;                           // shock crossing
-  // all_flux!'s zone search (all_flux.jl:68-72); one step can cross several of the thin zones
   const int ne = h.n_grid + 2;
-  int cand = -1;
-  if (p.x > p.x_old) {
-    for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { cand = j - 1; break; }
-  } else {
-    for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
+  const bool fwd = p.x > p.x_old;
+  // neighbour first -- its far edge, flow speed and field in ONE round of LDS reads; the zone search
+  // of all_flux! (all_flux.jl:68-72) stops there iff that edge is beyond x
+  int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
+  cand = cand < 0 ? 0 : (cand > ne - 2 ? ne - 2 : cand);
+  const double far = fwd ? S_x[cand + 1] : S_x[cand];
+  double ux_c = S_ux[cand], gd_c = S_gd[cand];
+  const double ux_3 = S_ux[p.ig3];
+  const bool adjacent = (fwd ? far > p.x : far <= p.x) && cand != p.i_grid;
+  if (!adjacent) {
+    // one step can cross several of the thin zones near the shock: the search loop
+    cand = -1;
+    if (fwd) {
+      for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { cand = j - 1; break; }
+    } else {
+      for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
+    }
+    if (cand < 0) return false;
+    ux_c = S_ux[cand]; gd_c = S_gd[cand];
   }
-  if (cand < 0 || cand <= h.i_grid_feb) return false;
-  if (S_ux[cand] != S_ux[p.ig3] || S_gd[cand] != p.gyro_denom) return false;
+  if (cand <= h.i_grid_feb) return false;
+  if (ux_c != ux_3 || gd_c != p.gyro_denom) return false;
   if (p.downstream && p.x < 0) p.inj = true;
   p.i_grid_old = p.i_grid;
   p.i_grid = cand;
@@ -1199,10 +1214,10 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
 
   const unsigned wv = threadIdx.x >> 6;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
-  p.pushed = false;
+  p.npush = 0;
   for (;;) {
-    ev_pending += (unsigned)__popcll(__ballot(p.pushed));
-    p.pushed = false;
+    ev_pending += (unsigned)(__popcll(__ballot(p.npush > 0)) + __popcll(__ballot(p.npush > 1)));
+    p.npush = 0;
     if (MCS_UNLIKELY(ev_pending >= 64u)) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
     // ---- refill idle lanes (wave-aggregated claim)
     const unsigned long long idle = __ballot(!active);
