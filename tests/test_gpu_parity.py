@@ -94,6 +94,37 @@ def test_oblique_field_tables():
     _lockstep(prob, N, 8)
 
 
+def modified_profile(prob, depth=0.3, scale_rg=50.0):
+    """A precursor: u_x falls smoothly from u0 to (1-depth) u0 ahead of the subshock, so u_x (and
+    gamma_sf) differs in every upstream zone near the shock -- what the reference's profile
+    smoothing produces after the first iteration.  Every zone crossing there needs transform_p_PSP."""
+    C = mcs.constants.C
+    x = prob.x_grid_cm
+    u0 = prob.ux[1]
+    up = x < 0
+    ux = prob.ux.copy()
+    ux[up] = u0 * (1 - depth * np.exp(x[up] / (scale_rg * prob.rg0)))
+    prob.ux = ux
+    prob.utot = np.hypot(prob.ux, prob.uz)
+    prob.gam_sf = 1 / np.sqrt(1 - (prob.utot / C) ** 2)
+    return prob
+
+
+def test_modified_shock_profile():
+    N = 900
+    prob = modified_profile(make_problem(N))
+    _lockstep(prob, N, 9)
+
+
+def test_modified_profile_with_energy_transfer():
+    ME_MP = mcs.constants.ME / mcs.constants.MP
+    N = 400
+    prob = make_problem(N, species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(ME_MP, -1.0, 1e6, 1.0)],
+                        energy_transfer_frac=0.2, radiation_losses=True)
+    modified_profile(prob)
+    _lockstep(prob, N, 6)
+
+
 def test_custom_epsB_flag_and_downstream_feb():
     N = 500
     prob = make_problem(N, FEB_downstream=(30.0, 0.0), b_field_turbulence=1.0)

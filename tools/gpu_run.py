@@ -7,8 +7,14 @@ import _mcs_loader; m = _mcs_loader.load()
 from mcs_amd import hip_backend
 N = int(sys.argv[1]); NPC = int(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+MOD = len(sys.argv) > 4 and sys.argv[4] == "mod"      # precursor profile: u_x differs in every upstream zone
 cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
 prob = m.inputs.build_problem(cfg)
+if MOD:
+    C = m.constants.C
+    x = prob.x_grid_cm; up = x < 0
+    ux = prob.ux.copy(); ux[up] = prob.ux[1] * (1 - 0.3 * np.exp(x[up] / (50.0 * prob.rg0)))
+    prob.ux = ux; prob.utot = np.hypot(prob.ux, prob.uz); prob.gam_sf = 1 / np.sqrt(1 - (prob.utot / C) ** 2)
 hb = hip_backend.HipBackend(0); hb.create(prob)
 if blocks: hb.set_launch(blocks, 256)
 hb.begin_iteration(1)
