@@ -850,13 +850,15 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
   p.x = p.x_old + dx;
   // same-zone test (all_flux.jl:64-82): one boundary compare in the common case
   const bool fwd = p.x > p.x_old;
-  const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
-  // the next threshold above x_old whose upward crossing means work: end of the grid, the PRP
-  // (prob_return.jl:73,89) or the downstream_test exit (x_dt, see refresh_dtest)
-  const double x_up = p.x_old < h.x_grid_stop ? h.x_grid_stop : (p.x_old < p.prp ? p.prp : p.x_dt);
+  const double z_lo = S_x[p.i_grid], z_hi = S_x[p.i_grid + 1];       // both edges, no branch (one ds_read2)
+  const bool same_zone = (fwd & (z_hi > p.x)) | (!fwd & (z_lo <= p.x));
+  // upward crossings that mean work: the end of the grid, the PRP (prob_return.jl:73,89) and the point
+  // beyond which downstream_test ends the particle (x_dt, see refresh_dtest).  Five compares and four
+  // scalar ops, no branch (a nested select compiles to exec-masked moves behind a 36-cycle skeleton).
+  const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
   const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);   // fine/coarse switch due
   ev_cross = !same_zone;
-  bool ev = (p.x >= x_up) | ev_xn;
+  bool ev = ev_up | ev_xn;
   if (h.odd_cfg) {   // wave-uniform: configurations with more per-pass conditions
     if (h.feb_down > 0) ev |= p.x > h.feb_down;
     if (h.dont_DSA || h.inj_frac < 1) ev |= p.x <= 0 && p.x_old > 0 && !p.inj;
@@ -1181,7 +1183,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   {
     int ob = 0;
     for (int i = threadIdx.x; i < ne; i += blockDim.x) ob |= S_bsin[i] != 0.0;
-    h.oblique = __syncthreads_or(ob) != 0;
+    h.oblique = __builtin_amdgcn_readfirstlane(__syncthreads_or(ob)) != 0;     // scalar: a uniform branch, not an exec mask
   }
   h.every_pass = h.custom_epsB || (h.rad_losses && h.aa < 1) || h.dont_scatter;
   h.odd_cfg = h.feb_down > 0 || h.dont_DSA || h.inj_frac < 1 || h.aa < 1 || h.n_xspec != 0;
