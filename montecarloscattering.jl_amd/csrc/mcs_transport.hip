@@ -1219,37 +1219,41 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.npush = 0;
   for (;;) {
-    ev_pending += (unsigned)(__popcll(__ballot(p.npush > 0)) + __popcll(__ballot(p.npush > 1)));
+    ev_pending += (unsigned)(__popcll(__builtin_amdgcn_ballot_w64(p.npush > 0)) + __popcll(__builtin_amdgcn_ballot_w64(p.npush > 1)));
     p.npush = 0;
-    if (MCS_UNLIKELY(ev_pending >= 64u)) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
-    // ---- refill idle lanes (wave-aggregated claim)
-    const unsigned long long idle = __ballot(!active);
-    if (MCS_UNLIKELY(idle != 0ull && !exhausted)) {
-      const int nidle = __popcll(idle);
-      const int leader = __ffsll((long long)idle) - 1;
-      unsigned long long base = 0;
-      if ((int)lane == leader) base = atomicAdd(a->work_counter, (unsigned long long)nidle);
-      base = __shfl(base, leader);
-      if (base >= n) {
-        exhausted = true;
-      } else if (!active) {
-        const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-        const unsigned long long idx = base + (unsigned long long)rank;
-        if (idx < n) {
-          k = (long long)idx;
-          load_particle(a, s, h, k, p, rng);
-          active = true; ev = false; ev_x = false; moved = false;
+    // ---- housekeeping behind ONE scalar branch: records to tally, idle lanes to refill, nothing left
+    const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
+    if (MCS_UNLIKELY(ev_pending >= 64u || (act_mask != ~0ull && !exhausted) || act_mask == 0ull)) {
+      if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
+      // refill idle lanes (wave-aggregated claim)
+      const unsigned long long idle = ~act_mask;
+      if (idle != 0ull && !exhausted) {
+        const int nidle = __popcll(idle);
+        const int leader = __ffsll((long long)idle) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(a->work_counter, (unsigned long long)nidle);
+        base = __shfl(base, leader);
+        if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
+          exhausted = true;
+        } else if (!active) {
+          const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+          const unsigned long long idx = base + (unsigned long long)rank;
+          if (idx < n) {
+            k = (long long)idx;
+            load_particle(a, s, h, k, p, rng);
+            active = true; ev = false; ev_x = false; moved = false;
+          }
         }
+        PROF_ADD(5, 1); PROF_ADD(6, nidle);
       }
-      PROF_ADD(5, 1); PROF_ADD(6, nidle);
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+        if (exhausted) break;
+        continue;
+      }
     }
     {
-      [[maybe_unused]] const int na__ = __popcll(__ballot(active));
+      [[maybe_unused]] const int na__ = __popcll(__builtin_amdgcn_ballot_w64(active));
       PROF_ADD(0, 1); PROF_ADD(8, na__);
-    }
-    if (MCS_UNLIKELY(__ballot(active) == 0ull)) {
-      if (exhausted) break;
-      continue;
     }
     double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
     // ---- the one rare region (see the comment above move_and_detect)
