@@ -1,5 +1,7 @@
-"""Phase profile of K1 (needs csrc/libmcs_hip_prof.so, built with -DMCS_PROF; run with
-MCS_HIP_LIB=libmcs_hip_prof.so): per pcut, wave-cycles and lane counts per loop phase.
+"""Event profile of K1 (needs csrc/libmcs_hip_prof.so = the library built with -DMCS_PROF added to
+TUNE; run with MCS_HIP_LIB=libmcs_hip_prof.so): per pcut, how often the rare region is entered and why.
+(Cycle timers were used during development and removed: an s_memtime read costs ~450 cycles and
+serialises the LDS queue, which distorts exactly what it is meant to measure.)
 usage: MCS_HIP_LIB=libmcs_hip_prof.so python tools/gpu_prof.py N NPC [first_pcut_to_print]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,13 +33,9 @@ for ip in range(1, NPC + 1):
     assert hb.lib.mcs_prof_read(prof.ctypes.data, 1) == 0
     P = prof.astype(np.float64)
     if ip >= FIRST:
-        passes = P[0]; tr = P[20] / max(passes, 1)          # cycles of one timer read
-        def cyc(slot, reads=1): return P[slot] - reads * tr * passes
-        tot = cyc(1, 4)
-        print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3):.3e}/s  (timer read = {tr:.0f} cyc)")
-        print(f"   wave passes {passes:.3e}, active lanes/pass {P[8]/passes:.1f}, passes with <=8 active {100*P[21]/passes:.1f} %, cycles/pass {tot/passes:.0f}")
-        print(f"   cycles/pass {tot/passes:.0f} (timer cost {tr:.0f}/read removed): drain {cyc(2)/passes:.0f}  refill {cyc(4)/passes:.0f}  rare region {cyc(7)/passes:.0f}  common pass {cyc(9)/passes:.0f}")
-        print(f"   inside rare (cycles per occurrence, timer removed): plain-crossing attempt {P[14]/max(P[12],1)-tr:.0f}; full path: post+block1 {P[17]/max(P[19],1)-tr:.0f}, pre {P[18]/max(P[19],1)-tr:.0f} ({P[19]/max(P[12],1):.2f} per entry); finish {P[30]/max(P[31],1)-tr:.0f} ({P[31]/max(P[12],1):.3f} per entry)")
+        passes = P[0]
+        print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3):.3e}/s")
+        print(f"   wave passes {passes:.3e}, live lanes/pass {P[8]/passes:.1f}")
         print(f"   rare region entered in {100*P[12]/passes:.1f} % of passes ({P[13]/max(P[12],1):.1f} lanes each); full path for {P[16]/max(P[12],1):.2f} lanes per entry")
         e = max(P[12], 1)
         print(f"   lanes per entry with: xn switch due {P[22]/e:.2f}, x>=x_up {P[23]/e:.2f}, time event {P[24]/e:.2f}, refresh flags {P[25]/e:.2f}, crossing not plain {P[26]/e:.2f}, near FEB {P[27]/e:.2f}, to be saved {P[28]/e:.2f}, new particle {P[29]/e:.2f}")
