@@ -775,10 +775,11 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
 // to < 64 at the top of every pass and one pass adds at most two records per lane -- one for the move
 // of the previous common pass and one for a Code Block 1 move (a second PRP return cannot follow
 // directly: the retro walk leaves the particle AT the PRP, and a return needs x_old < prp).
-__device__ __forceinline__ void push_record(Pt& p, int ig3) {
-  const unsigned long long m_ev = __ballot(1);                 // lanes that are here now
+// `known_base` >= 0: the stack height is known (first push site of the pass: the register mirror), no LDS read.
+__device__ __forceinline__ void push_record(Pt& p, int ig3, int known_base = -1) {
+  const unsigned long long m_ev = __builtin_amdgcn_ballot_w64(true);   // lanes that are here now
   const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-  const unsigned base = S_evcur[wv];
+  const unsigned base = known_base >= 0 ? (unsigned)known_base : S_evcur[wv];
   const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
   S_evf[wv][0][pos] = p.pb_pf; S_evf[wv][1][pos] = p.p_perp; S_evf[wv][2][pos] = p.ptot_pf; S_evf[wv][3][pos] = p.gam_pf;
   S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
@@ -1087,19 +1088,20 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
 // the FEB zone).  What slow_post + slow_pre would do then is: inj update (particle_loop.jl:433-435),
 // the all_flux record (all_flux.jl:68-82, 130-137) and the zone reload of the next Code Block 3
 // (particle_loop.jl:186-204); every exit test is known to be false.  Returns false if it is not that case.
-__device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
-  if (p.x_old < 0 && p.x >= 0) return false;                           // shock crossing
+__device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsigned stack_height) {
   const int ne = h.n_grid + 2;
   const bool fwd = p.x > p.x_old;
   // neighbour first -- its far edge, flow speed and field in ONE round of LDS reads; the zone search
-  // of all_flux! (all_flux.jl:68-72) stops there iff that edge is beyond x
+  // of all_flux! (all_flux.jl:68-72) stops there iff that edge is beyond x.  All tests feed one
+  // predicate: no early return, one conditional region for the commit.
   int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
   cand = cand < 0 ? 0 : (cand > ne - 2 ? ne - 2 : cand);
   const double far = fwd ? S_x[cand + 1] : S_x[cand];
   double ux_c = S_ux[cand], gd_c = S_gd[cand];
   const double ux_3 = S_ux[p.ig3];
   const bool adjacent = (fwd ? far > p.x : far <= p.x) && cand != p.i_grid;
-  if (!adjacent) {
+  const bool shock = p.x_old < 0 && p.x >= 0;
+  if (MCS_UNLIKELY(!adjacent && !shock)) {
     // one step can cross several of the thin zones near the shock: the search loop
     cand = -1;
     if (fwd) {
@@ -1107,17 +1109,21 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p) {
     } else {
       for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
     }
-    if (cand < 0) return false;
-    ux_c = S_ux[cand]; gd_c = S_gd[cand];
+    const int c = cand < 0 ? 0 : cand;
+    ux_c = S_ux[c]; gd_c = S_gd[c];
   }
-  if (cand <= h.i_grid_feb) return false;
-  if (ux_c != ux_3 || gd_c != p.gyro_denom) return false;
-  if (p.downstream && p.x < 0) p.inj = true;
-  p.i_grid_old = p.i_grid;
-  p.i_grid = cand;
-  push_record(p, p.ig3);
-  p.ig3 = cand;
-  return true;
+  const bool ok = !shock && cand >= 0 && cand > h.i_grid_feb && ux_c == ux_3 && gd_c == p.gyro_denom;
+  // the first push site of a pass: every lane that pushes here is in this call together
+  const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
+  if (ok) {
+    if (p.downstream && p.x < 0) p.inj = true;
+    p.i_grid_old = p.i_grid;
+    p.i_grid = cand;
+    push_record(p, p.ig3, (int)stack_height);
+    p.ig3 = cand;
+  }
+  (void)m_ok;
+  return ok;
 }
 
 }  // namespace
@@ -1264,7 +1270,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
       PROF_ADD(12, 1);
       int end = -1;
       bool full = unusual || ev || h.etf || h.custom_epsB;
-      if (!full) full = !plain_crossing(a, h, p);
+      if (!full) full = !plain_crossing(a, h, p, ev_pending);
       PROF_LANES(16, full);
 #ifdef MCS_PROF
       {
