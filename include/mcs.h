@@ -213,6 +213,13 @@ int64_t mcs_pop_size(mcs_ctx* ctx);
 int mcs_init_pop(mcs_ctx* ctx, int64_t n, int64_t j_offset, int64_t n_total,
                  const double* ptot_pf_in, const double* weight_in,
                  double x_start_cm, int i_grid_start, int relativistic, int fast_push);
+/* The same from the host's momentum discretisation instead of per-particle arrays (set_inj_dist,
+ * src/initializers.jl:1251-1328, gives every particle of a bin the same ptot and weight): particle j
+ * (global, 0-based) lies in the bin b with bin_start[b] <= j < bin_start[b+1]; bin_start has n_bins+1
+ * entries, bin_start[n_bins] = n_total.  O(bins) host work and upload instead of O(N). */
+int mcs_init_pop_binned(mcs_ctx* ctx, int64_t n_local, int64_t j_offset, int64_t n_total, int n_bins,
+                        const double* bin_ptot_pf, const double* bin_weight, const int64_t* bin_start,
+                        double x_start_cm, int i_grid_start, int relativistic, int fast_push);
 
 /* K1: the particle loop of one pcut over the resident population.
  * i_prt_offset: global index of local particle 0 minus 1 (multi-GPU shards;

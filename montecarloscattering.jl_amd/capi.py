@@ -214,6 +214,7 @@ def load_library() -> ct.CDLL:
         "mcs_saved_download": (i32, [vp, i64, soa_p, c_uint8_p]),
         "mcs_pop_size": (i64, [vp]),
         "mcs_init_pop": (i32, [vp, i64, i64, i64, c_double_p, c_double_p, dbl, i32, i32, i32]),
+        "mcs_init_pop_binned": (i32, [vp, i64, i64, i64, i32, c_double_p, c_double_p, c_int64_p, dbl, i32, i32, i32]),
         "mcs_run_pcut": (i32, [vp, i32, i64, c_int64_p]),
         "mcs_new_pcut": (i32, [vp, i64, c_int64_p]),
         "mcs_run_pcut_host": (i32, [vp, i32, i64, i64, soa_p, soa_p, c_uint8_p, c_int64_p]),
@@ -239,7 +240,7 @@ EXPORTED_SYMBOLS = [
     "mcs_abi_version", "mcs_last_error", "mcs_create", "mcs_destroy", "mcs_sync", "mcs_bind_tallies",
     "mcs_tallies_f64_devptr", "mcs_tallies_i64_devptr", "mcs_set_grid", "mcs_set_cuts", "mcs_begin_iteration",
     "mcs_begin_species", "mcs_set_fluxes", "mcs_pop_upload", "mcs_pop_download", "mcs_saved_download",
-    "mcs_pop_size", "mcs_init_pop", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
+    "mcs_pop_size", "mcs_init_pop", "mcs_init_pop_binned", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
 ]

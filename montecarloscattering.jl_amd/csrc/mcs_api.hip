@@ -24,6 +24,7 @@ hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, De
 hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
                                long long n_total, unsigned long long key, double m, double u, double x_start,
                                int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
+                               int n_bins, const double* bin_ptot, const double* bin_weight, const long long* bin_start,
                                hipStream_t st);
 hipError_t mcs_launch_fill(double* p, long long n, double v, hipStream_t st);
 hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStream_t st);
@@ -424,8 +425,42 @@ int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const
     HIPCHK(hipMemcpyAsync(c->d_stage + n, weight_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned long long key = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_ions + (c->i_ion - 1));
     HIPCHK(mcs_launch_init_pop(c->cur.d, c->d_stage, c->d_stage + n, n, j_offset, n_total, key, c->m, c->h_ux[i_grid_start],
-                               x_start_cm, i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, c->stream));
+                               x_start_cm, i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, 0, nullptr, nullptr, nullptr,
+                               c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->n = n;
+  return 0;
+}
+
+int mcs_init_pop_binned(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, int n_bins, const double* bin_ptot_pf,
+                        const double* bin_weight, const int64_t* bin_start, double x_start_cm, int i_grid_start,
+                        int relativistic, int fast_push) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->have_grid) return fail("mcs_init_pop_binned: call mcs_set_grid first");
+  if (n < 0 || n_bins < 1 || n_bins > 4096 || i_grid_start < 0 || i_grid_start > c->P.n_grid || !bin_ptot_pf || !bin_weight || !bin_start)
+    return fail("mcs_init_pop_binned: bad arguments");
+  if (bin_start[0] != 0 || bin_start[n_bins] != n_total || j_offset < 0 || j_offset + n > n_total)
+    return fail("mcs_init_pop_binned: bin_start must run from 0 to n_total and the shard must lie inside");
+  for (int b = 0; b < n_bins; ++b) {
+    if (bin_start[b + 1] < bin_start[b]) return fail("mcs_init_pop_binned: bin_start must be non-decreasing");
+    if (bin_start[b + 1] > bin_start[b] && !(bin_ptot_pf[b] > 0)) return fail("mcs_init_pop_binned: ptot_pf must be > 0 (reference quirk G6)");
+  }
+  c->n = 0;
+  if (ensure_capacity(c, n)) return 1;
+  const size_t nd = (size_t)3 * n_bins + 1;      // ptot | weight | start (int64 in a double slot)
+  if (ensure_stage(c, (long long)nd + 2)) return 1;
+  if (n > 0) {
+    std::vector<double> h(nd);
+    std::memcpy(h.data(), bin_ptot_pf, sizeof(double) * n_bins);
+    std::memcpy(h.data() + n_bins, bin_weight, sizeof(double) * n_bins);
+    std::memcpy(h.data() + 2 * n_bins, bin_start, sizeof(int64_t) * (n_bins + 1));
+    HIPCHK(hipMemcpyAsync(c->d_stage, h.data(), nd * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned long long key = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_ions + (c->i_ion - 1));
+    HIPCHK(mcs_launch_init_pop(c->cur.d, nullptr, nullptr, n, j_offset, n_total, key, c->m, c->h_ux[i_grid_start], x_start_cm,
+                               i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, n_bins, c->d_stage,
+                               c->d_stage + n_bins, (const long long*)(c->d_stage + 2 * n_bins), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));     // h goes out of scope
   }
   c->n = n;
   return 0;

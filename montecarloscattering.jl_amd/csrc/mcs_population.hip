@@ -135,11 +135,22 @@ mcs_k_split(DevPop sv, DevPop out, const long long* __restrict__ src, long long 
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_init_pop(DevPop out, const double* __restrict__ ptot_in, const double* __restrict__ weight_in, long long n,
                long long j_offset, long long n_total, unsigned long long key, double m, double u, double x_start,
-               int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop) {
+               int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
+               int n_bins, const double* __restrict__ bin_ptot, const double* __restrict__ bin_weight,
+               const long long* __restrict__ bin_start) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const long long j = j_offset + k;
-  const double ptot = ptot_in[k];
+  double ptot, wgt;
+  if (n_bins > 0) {
+    // binned form (the momentum discretisation of set_inj_dist, initializers.jl:1251-1328): particle j
+    // belongs to the bin b with bin_start[b] <= j < bin_start[b+1]
+    int lo = 0, hi = n_bins;                 // invariant: bin_start[lo] <= j < bin_start[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bin_start[mid] <= j) lo = mid; else hi = mid; }
+    ptot = bin_ptot[lo]; wgt = bin_weight[lo];
+  } else {
+    ptot = ptot_in[k]; wgt = weight_in[k];
+  }
   const double U = philox_uniform(key, 0x504F50u, (unsigned long long)j);
   const double beta_u = u / CC_;
   double pb;
@@ -160,7 +171,7 @@ mcs_k_init_pop(DevPop out, const double* __restrict__ ptot_in, const double* __r
     const double vx_pf = vx_sf - u;
     pb = 1.0 * m * vx_pf;
   }
-  out.weight[k] = weight_in[k];
+  out.weight[k] = wgt;
   out.ptot_pf[k] = ptot;
   out.pb_pf[k] = pb;
   out.x_PT_cm[k] = x_start;
@@ -222,10 +233,12 @@ hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, De
 hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
                                long long n_total, unsigned long long key, double m, double u, double x_start,
                                int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
+                               int n_bins, const double* bin_ptot, const double* bin_weight, const long long* bin_start,
                                hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(mcs_k_init_pop, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, ptot_in, weight_in, n,
-                     j_offset, n_total, key, m, u, x_start, i_grid_start, relativistic, fast_push, xn_per_fine, x_grid_stop);
+                     j_offset, n_total, key, m, u, x_start, i_grid_start, relativistic, fast_push, xn_per_fine, x_grid_stop,
+                     n_bins, bin_ptot, bin_weight, bin_start);
   return hipGetLastError();
 }
 

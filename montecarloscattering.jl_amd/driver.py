@@ -203,7 +203,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                         backend.write_tallies(np.zeros_like(G_f), np.zeros_like(G_i))
                 else:
                     G_f, G_i = f, i
-            per_species.append((i_iter, i_ion, G_f.copy(), G_i.copy()))
+            per_species.append((i_iter, i_ion, G_f, G_i))      # fresh host arrays: no copy needed
             if on_species_end is not None:
                 on_species_end(i_iter, i_ion, G_f, G_i)
 

@@ -93,6 +93,16 @@ class HipBackend:
 
     # -- population
     def init_pop(self, inj, j_offset, n_local, n_total):
+        """K3 from the binned momentum discretisation: O(bins) host work and upload, whatever N."""
+        bp = np.ascontiguousarray(inj.bin_ptot, dtype=np.float64)
+        bw = np.ascontiguousarray(inj.bin_weight, dtype=np.float64)
+        bs = np.ascontiguousarray(inj.bin_start, dtype=np.int64)
+        self._chk(self.lib.mcs_init_pop_binned(self.h, n_local, j_offset, n_total, len(bp), _dp(bp), _dp(bw),
+                                               bs.ctypes.data_as(c_int64_p), inj.x_start_cm, inj.i_grid_start,
+                                               int(inj.relativistic), int(inj.fast_push)))
+
+    def init_pop_arrays(self, inj, j_offset, n_local, n_total):
+        """K3 from per-particle arrays (the reference's own form of the call)."""
         ptot = np.ascontiguousarray(inj.ptot_pf[j_offset:j_offset + n_local], dtype=np.float64)
         w = np.ascontiguousarray(inj.weight[j_offset:j_offset + n_local], dtype=np.float64)
         self._chk(self.lib.mcs_init_pop(self.h, n_local, j_offset, n_total, _dp(ptot), _dp(w), inj.x_start_cm,

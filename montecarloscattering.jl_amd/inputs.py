@@ -273,8 +273,10 @@ def create_inj_dist_momentum_range(m: float, T: float, nbins: int) -> np.ndarray
     return p_min + dp * np.arange(nbins + 1)
 
 
-def set_inj_dist(inj_weight: bool, n_pts_inj: int, inp_distr: int, T_or_E: float, m: float, n0: float):
-    """src/initializers.jl:1251-1328 -> (ptot[n], weight[n], n).
+def set_inj_dist_bins(inj_weight: bool, n_pts_inj: int, inp_distr: int, T_or_E: float, m: float, n0: float):
+    """src/initializers.jl:1251-1328 in binned form -> (bin_ptot[b], bin_weight[b], bin_count[b]):
+    every particle of bin b gets ptot = bin_ptot[b] and weight = bin_weight[b]; the per-particle
+    arrays of the reference are np.repeat of these (set_inj_dist below).  O(bins) work.
 
     Deviation (quirk G6): the equal-weight loop starts its counter at 0, not 1, so
     there is no zero-momentum first particle (with scattering enabled that particle
@@ -286,8 +288,9 @@ def set_inj_dist(inj_weight: bool, n_pts_inj: int, inp_distr: int, T_or_E: float
         E0 = m * C * C
         p = math.sqrt(2 * m * E_inj) if E_inj / E0 < E_REL_PT else math.sqrt(E_inj ** 2 - E0 ** 2) / C
         # as coded: weight = n0 / n_pts_tot with n_pts_tot from the (discarded) M-B pass
-        _, _, n_tot = set_inj_dist(inj_weight, n_pts_inj, 1, 1e6, m, n0)
-        return np.full(n_pts_inj, p), np.full(n_pts_inj, n0 / n_tot), n_pts_inj
+        _, _, cnt = set_inj_dist_bins(inj_weight, n_pts_inj, 1, 1e6, m, n0)
+        n_tot = int(cnt.sum())
+        return np.array([p]), np.array([n0 / n_tot]), np.array([n_pts_inj], dtype=np.int64)
     p_range = create_inj_dist_momentum_range(m, T_or_E, NUM_THERM_BINS)
     E0 = m * C * C
     kT = KB * T_or_E
@@ -302,16 +305,18 @@ def set_inj_dist(inj_weight: bool, n_pts_inj: int, inp_distr: int, T_or_E: float
     if inj_weight:
         area_per_pt = area_tot / n_pts_inj
         counts = np.rint(bin_area / area_per_pt).astype(np.int64)   # round(Int, .) = ties-to-even
-        ptot = np.repeat(centers, counts)
         n = int(counts.sum())
-        weight = np.full(n, n0 / n)
-        return ptot, weight, n
+        return centers, np.full(len(centers), n0 / n), counts
     n_per_bin = n_pts_inj // NUM_THERM_BINS
     if n_per_bin < 5:
         raise ValueError("too few particles per bin; increase n_pts_inj")
-    ptot = np.repeat(centers, n_per_bin)
-    weight = np.repeat(bin_area / area_tot / n_per_bin * n0, n_per_bin)
-    return ptot, weight, n_per_bin * NUM_THERM_BINS
+    return centers, bin_area / area_tot / n_per_bin * n0, np.full(len(centers), n_per_bin, dtype=np.int64)
+
+
+def set_inj_dist(inj_weight: bool, n_pts_inj: int, inp_distr: int, T_or_E: float, m: float, n0: float):
+    """src/initializers.jl:1251-1328 -> (ptot[n], weight[n], n): the per-particle arrays."""
+    bp, bw, cnt = set_inj_dist_bins(inj_weight, n_pts_inj, inp_distr, T_or_E, m, n0)
+    return np.repeat(bp, cnt), np.repeat(bw, cnt), int(cnt.sum())
 
 
 @dataclasses.dataclass
@@ -548,10 +553,13 @@ def build_problem(cfg: Config) -> Problem:
 
 @dataclasses.dataclass
 class Injection:
-    """Host part of init_pop (src/initializers.jl:977-1134) for one species."""
+    """Host part of init_pop (src/initializers.jl:977-1134) for one species.  The momentum
+    discretisation is kept in binned form (O(bins)); `ptot_pf` / `weight` expand it to the
+    reference's per-particle arrays on demand (CPU oracle, tests)."""
     n_pts_use: int
-    ptot_pf: np.ndarray
-    weight: np.ndarray
+    bin_ptot: np.ndarray
+    bin_weight: np.ndarray
+    bin_count: np.ndarray
     x_start_cm: float
     i_grid_start: int
     relativistic: bool
@@ -559,6 +567,18 @@ class Injection:
     pxx_flux: np.ndarray
     pxz_flux: np.ndarray
     energy_flux: np.ndarray
+
+    @property
+    def bin_start(self) -> np.ndarray:
+        return np.concatenate([[0], np.cumsum(self.bin_count)]).astype(np.int64)
+
+    @property
+    def ptot_pf(self) -> np.ndarray:
+        return np.repeat(self.bin_ptot, self.bin_count)
+
+    @property
+    def weight(self) -> np.ndarray:
+        return np.repeat(self.bin_weight, self.bin_count)
 
 
 def init_pop_host(prob: Problem, i_ion: int) -> Injection:
@@ -570,9 +590,9 @@ def init_pop_host(prob: Problem, i_ion: int) -> Injection:
     zeros = np.zeros(ng)
     if not cfg.fast_upstream_transport:
         T_or_E = sp.temperature if cfg.input_distribution == 1 else cfg.injection_energy
-        ptot, w, n = set_inj_dist(cfg.injection_weights, cfg.N_PTS_INJ, cfg.input_distribution, T_or_E, sp.mass, sp.density)
+        bp, bw, cnt = set_inj_dist_bins(cfg.injection_weights, cfg.N_PTS_INJ, cfg.input_distribution, T_or_E, sp.mass, sp.density)
         x0 = cfg.x_grid_limits[0] * prob.rg0 - 10 * prob.rg0 * cfg.gyrofactor
-        return Injection(n, ptot, w, x0, 0, False, False, zeros, zeros.copy(), zeros.copy())
+        return Injection(int(cnt.sum()), bp, bw, cnt, x0, 0, False, False, zeros, zeros.copy(), zeros.copy())
     if cfg.input_distribution > 1:
         raise ValueError("fast push will only work with thermal input distr.")
     i_stop = prob.i_fast_stop
@@ -602,6 +622,6 @@ def init_pop_host(prob: Problem, i_ion: int) -> Injection:
                 Fpx = P_c + gb ** 2 * (e_c + Xi * P_c)
                 Fen = gb * g_c * C * (e_c + Xi * P_c) - gb * C * e_c
             pxx[i - 1], en[i - 1] = Fpx, Fen
-    ptot, w, n = set_inj_dist(cfg.injection_weights, cfg.N_PTS_INJ, cfg.input_distribution,
-                              sp.temperature * temp_ratio, sp.mass, sp.density)
-    return Injection(n, ptot, w, prob.x_fast_stop_rg * prob.rg0, i_stop, relativistic, True, pxx, pxz, en)
+    bp, bw, cnt = set_inj_dist_bins(cfg.injection_weights, cfg.N_PTS_INJ, cfg.input_distribution,
+                                    sp.temperature * temp_ratio, sp.mass, sp.density)
+    return Injection(int(cnt.sum()), bp, bw, cnt, prob.x_fast_stop_rg * prob.rg0, i_stop, relativistic, True, pxx, pxz, en)

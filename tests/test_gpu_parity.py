@@ -132,6 +132,30 @@ def test_custom_epsB_flag_and_downstream_feb():
     _lockstep(prob, N, 8)
 
 
+def test_init_pop_binned_equals_per_particle_arrays():
+    """mcs_init_pop_binned (O(bins) upload, what the driver uses) against mcs_init_pop on the expanded
+    per-particle arrays (the reference's form of the call), whole population and a shard of it."""
+    N = 5000
+    prob = make_problem(N)
+    inj = mcs.inputs.init_pop_host(prob, 1)
+    n = inj.n_pts_use
+    assert np.array_equal(np.repeat(inj.bin_ptot, inj.bin_count), inj.ptot_pf) and inj.bin_start[-1] == n
+    hb = hip_backend(prob)
+    for lo, hi in ((0, n), (1234, 4321)):
+        start_species(hb, prob)
+        hb.init_pop(inj, lo, hi - lo, n)
+        a = hb.get_population()
+        hb.init_pop_arrays(inj, lo, hi - lo, n)
+        assert_pop_equal(a, hb.get_population(), f"binned vs arrays, shard [{lo},{hi})")
+    # argument checks
+    bs = inj.bin_start.copy(); bs[-1] += 1
+    rc = hb.lib.mcs_init_pop_binned(hb.h, n, 0, n, len(inj.bin_ptot), inj.bin_ptot.ctypes.data_as(mcs.capi.c_double_p),
+                                    inj.bin_weight.ctypes.data_as(mcs.capi.c_double_p), bs.ctypes.data_as(mcs.capi.c_int64_p),
+                                    inj.x_start_cm, inj.i_grid_start, int(inj.relativistic), int(inj.fast_push))
+    assert rc != 0 and b"bin_start" in hb.lib.mcs_last_error()
+    hb.destroy()
+
+
 def test_host_buffer_drop_in_call():
     """mcs_run_pcut_host(in, saved_out, l_save): the literal replacement of the loop at
     src/main_loops.jl:228-292 gives the same arrays as the resident path."""
