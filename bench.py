@@ -86,12 +86,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # Rehearsal knobs (tests of the N > 1 code path on a one-GPU box): every rank on one device, gloo
+    # instead of RCCL.  Never set by the driver.
+    if "MCS_BENCH_ONE_DEVICE" in os.environ:
+        local = int(os.environ["MCS_BENCH_ONE_DEVICE"])
+    backend = os.environ.get("MCS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_global = args.particles * world
     n_itrs = args.steps + args.warmup
