@@ -158,10 +158,16 @@ MCS_HD double asin(double x) {
 struct HotCoef {
   double S0, S1, S2, S3, S4, S5;          /* MCS_SIN_0..5 */
   double C0, C1, C2, C3, C4, C5;          /* MCS_COS_0..5 */
-  double A0, A1, A2, A3, A4, A5;   /* MCS_ASIN_0..5 (6..12 stay literals: registers are scarcer than s_mov) */
+  double A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11, A12;   /* MCS_ASIN_0..12 */
+  double R0, R1, R2, R3;                  /* 2/pi and the three parts of pi/2 (Cody-Waite reduction) */
 };
 MCS_HD void sincos_t(double x, double* s, double* c, const HotCoef& k) {
-  int n; double r = reduce_pio2(x, &n);
+  /* reduce_pio2 with its four constants from the table: same operations, same order */
+  const double kk = __builtin_rint(x * k.R0);
+  double r = fma_(-kk, k.R1, x);
+  r = fma_(-kk, k.R2, r);
+  r = fma_(-kk, k.R3, r);
+  const int n = (int)kk & 3;
   const double z = r * r;
   double ps = k.S5;
   ps = fma_(ps, z, k.S4); ps = fma_(ps, z, k.S3); ps = fma_(ps, z, k.S2); ps = fma_(ps, z, k.S1); ps = fma_(ps, z, k.S0);
@@ -179,9 +185,9 @@ MCS_HD double asin_t(double x, const HotCoef& k) {
   bool small = ax < 0.5;
   double z = small ? x * x : (1.0 - ax) * 0.5;
   double s = small ? ax : sqrt_(z);
-  double p = MCS_SC(MCS_ASIN_12);
-  p = fma_(p, z, MCS_SC(MCS_ASIN_11)); p = fma_(p, z, MCS_SC(MCS_ASIN_10)); p = fma_(p, z, MCS_SC(MCS_ASIN_9)); p = fma_(p, z, MCS_SC(MCS_ASIN_8)); p = fma_(p, z, MCS_SC(MCS_ASIN_7));
-  p = fma_(p, z, MCS_SC(MCS_ASIN_6)); p = fma_(p, z, k.A5); p = fma_(p, z, k.A4); p = fma_(p, z, k.A3); p = fma_(p, z, k.A2);
+  double p = k.A12;
+  p = fma_(p, z, k.A11); p = fma_(p, z, k.A10); p = fma_(p, z, k.A9); p = fma_(p, z, k.A8); p = fma_(p, z, k.A7);
+  p = fma_(p, z, k.A6); p = fma_(p, z, k.A5); p = fma_(p, z, k.A4); p = fma_(p, z, k.A3); p = fma_(p, z, k.A2);
   p = fma_(p, z, k.A1); p = fma_(p, z, k.A0);
   double t = fma_(s * z, p, s);
   double big = MCS_SC(MCS_PIO2_DD_0) - (2.0 * t - MCS_SC(MCS_PIO2_DD_1));

@@ -228,7 +228,8 @@ __device__ __forceinline__ void ladd_i32(int* p, int v) {
 // Event counters are bumped in LDS (one ds_add_u32) and flushed once per block: a
 // per-particle global atomic on ONE address serialises at ~12 ns each (1e6 particles = 12 ms).
 __shared__ unsigned int g_ctr[MCS_IC_COUNT + 1];
-__shared__ double g_sc[8];   // [0..3] layout.scalars, [4] esc_flux, [5] px_esc_feb, [6] energy_esc_feb (this ion/iter)
+__shared__ double g_sc[8];
+__shared__ unsigned long long S_steps[3];   // helix steps, retro steps, RNG draws of the particles this block finished   // [0..3] layout.scalars, [4] esc_flux, [5] px_esc_feb, [6] energy_esc_feb (this ion/iter)
 
 // ---- optional phase profile (-DMCS_PROF; tools/gpu_prof.py): cycle / lane counts per loop phase
 #ifdef MCS_PROF
@@ -1166,6 +1167,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   for (int i = threadIdx.x; i < MCS_MAXNE; i += blockDim.x) S_nc[i] = 0;
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
   if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
+  if (threadIdx.x < 3) S_steps[threadIdx.x] = 0ull;
   if (threadIdx.x < 4) S_evcur[threadIdx.x] = 0u;
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF) S_prof[threadIdx.x] = 0ull;
@@ -1194,14 +1196,17 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   h.every_pass = h.custom_epsB || (h.rad_losses && h.aa < 1) || h.dont_scatter;
   h.odd_cfg = h.feb_down > 0 || h.dont_DSA || h.inj_frac < 1 || h.aa < 1 || h.n_xspec != 0;
 
-  // the 18 hottest polynomial coefficients of the per-step sincos + asin, resident in VGPRs
+  // the 29 constants of the per-step sincos + asin, resident in VGPRs
   mcsm::HotCoef kc;
   kc.S0 = vconst(MCS_SIN_0); kc.S1 = vconst(MCS_SIN_1); kc.S2 = vconst(MCS_SIN_2); kc.S3 = vconst(MCS_SIN_3);
   kc.S4 = vconst(MCS_SIN_4); kc.S5 = vconst(MCS_SIN_5);
   kc.C0 = vconst(MCS_COS_0); kc.C1 = vconst(MCS_COS_1); kc.C2 = vconst(MCS_COS_2); kc.C3 = vconst(MCS_COS_3);
   kc.C4 = vconst(MCS_COS_4); kc.C5 = vconst(MCS_COS_5);
   kc.A0 = vconst(MCS_ASIN_0); kc.A1 = vconst(MCS_ASIN_1); kc.A2 = vconst(MCS_ASIN_2); kc.A3 = vconst(MCS_ASIN_3);
-  kc.A4 = vconst(MCS_ASIN_4); kc.A5 = vconst(MCS_ASIN_5);
+  kc.A4 = vconst(MCS_ASIN_4); kc.A5 = vconst(MCS_ASIN_5); kc.A6 = vconst(MCS_ASIN_6); kc.A7 = vconst(MCS_ASIN_7);
+  kc.A8 = vconst(MCS_ASIN_8); kc.A9 = vconst(MCS_ASIN_9); kc.A10 = vconst(MCS_ASIN_10); kc.A11 = vconst(MCS_ASIN_11);
+  kc.A12 = vconst(MCS_ASIN_12);
+  kc.R0 = vconst(MCS_TWO_OVER_PI); kc.R1 = vconst(MCS_PIO2_0); kc.R2 = vconst(MCS_PIO2_1); kc.R3 = vconst(MCS_PIO2_2);
 
   Pt p;
   Rng rng;
@@ -1217,7 +1222,6 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   bool moved = false;     // this lane's particle has made a move since it was loaded
   double phi_prev = 0.0;  // phase before the last move (the no-DSA retry loop needs it)
   long long k = -1;
-  unsigned long long c_helix = 0, c_retro = 0, c_draws = 0;
   const unsigned lane = __lane_id();
   const unsigned long long n = (unsigned long long)a->n;
 
@@ -1300,7 +1304,9 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
       if (end >= 0) {
         PROF_ADD(10, 1);
         const int steps = p.helix > MCS_HELIX_CAP ? MCS_HELIX_CAP : p.helix;
-        c_helix += (unsigned long long)steps; c_retro += (unsigned long long)p.n_retro; c_draws += rng.n;
+        // step totals: three LDS atomics per particle END instead of three 64-bit registers per lane
+        atomicAdd(&S_steps[0], (unsigned long long)steps); atomicAdd(&S_steps[1], (unsigned long long)p.n_retro);
+        atomicAdd(&S_steps[2], (unsigned long long)rng.n);
         if (p.n_ovr) cnt(a, MCS_IC_TCUT_OVERRUN, p.n_ovr);
         if (end == 0) {
           a->l_save[k] = 1;
@@ -1335,22 +1341,16 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     moved = true;
   }
 
-  // ---- flush per-lane counters (wave reduce) and the LDS staging
-  for (int off = 32; off > 0; off >>= 1) {
-    c_helix += __shfl_down(c_helix, off);
-    c_retro += __shfl_down(c_retro, off);
-    c_draws += __shfl_down(c_draws, off);
-  }
+  // ---- the wave's remaining tally records, then the LDS staging
   drain_events(a, s, wv, lane, true);
-  if (lane == 0) {   // 64-bit totals go straight to the global counters (one atomic per wave)
-    if (c_helix) gadd_u64(&a->I[ng + MCS_IC_STEPS_HELIX], c_helix);
-    if (c_retro) gadd_u64(&a->I[ng + MCS_IC_STEPS_RETRO], c_retro);
-    if (c_draws) gadd_u64(&a->I[ng + MCS_IC_RNG_DRAWS], c_draws);
-  }
   __syncthreads();
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF && S_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], S_prof[threadIdx.x]);
 #endif
+  if (threadIdx.x < 3 && S_steps[threadIdx.x]) {   // one global atomic per block and counter
+    const int which = threadIdx.x == 0 ? MCS_IC_STEPS_HELIX : (threadIdx.x == 1 ? MCS_IC_STEPS_RETRO : MCS_IC_RNG_DRAWS);
+    gadd_u64(&a->I[ng + which], S_steps[threadIdx.x]);
+  }
   if (threadIdx.x < MCS_IC_COUNT) {
     const unsigned int c = g_ctr[threadIdx.x];
     if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
