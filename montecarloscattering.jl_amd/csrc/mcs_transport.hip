@@ -199,6 +199,9 @@ struct Pt {
   double rg_val;                 // refined 1/(gam_pf*m)
   double x_dt;                   // downstream_test exit threshold (refresh_dtest)
   double t_ev;                   // min(next time cut, age_max): the clock compares against one number
+  // properties of zone ig3 (gamma_sf, cos theta_B, u_x, gamma_ef) and the edges of zone i_grid: read
+  // from the LDS tables when the zone changes (rare code), not in every pass
+  double z_gsf, z_bcos, z_ux, z_gef, z_lo, z_hi;
   int flags;
   int ovr_inc;                   // 1 while downstream past the last time cut (D4 counter), else 0
   unsigned n_ovr;                // passes counted by D4, flushed when the particle ends
@@ -733,6 +736,12 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
   }
 }
 
+__device__ __forceinline__ void load_zone_props(Pt& p) {
+  const int z = p.ig3;
+  p.z_gsf = S_gsf[z]; p.z_bcos = S_bcos[z]; p.z_ux = S_ux[z]; p.z_gef = S_gef[z];
+}
+__device__ __forceinline__ void load_zone_edges(Pt& p) { p.z_lo = S_x[p.i_grid]; p.z_hi = S_x[p.i_grid + 1]; }
+
 // load a particle and run the prologue of particle_loop (src/particle_loop.jl:44-153)
 __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h, long long k, Pt& p, Rng& rng) {
   p.weight = a->in.weight[k];
@@ -750,6 +759,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.inj = (meta >> 25) & 1u;
   p.i_grid_old = p.i_grid;
   p.ig3 = p.i_grid;
+  load_zone_props(p); load_zone_edges(p);
   p.helix = 0; p.n_retro = 0;
   const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
   rng.init(key);
@@ -835,7 +845,7 @@ __device__ __forceinline__ void refresh_dtest(CK* a, const Hot& h, Pt& p) {
 // needs slow_post.  Straight-line; `oblique` is wave-uniform (some zone has b_sin != 0).
 __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross) {
   const int ig3 = p.ig3;
-  const double gsf = S_gsf[ig3], bcos = S_bcos[ig3], ux = S_ux[ig3];
+  const double gsf = p.z_gsf, bcos = p.z_bcos, ux = p.z_ux;
   p.x_old = p.x;
   const double phi_old = p.phi;
   phi_old_out = phi_old;
@@ -852,8 +862,7 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
   p.x = p.x_old + dx;
   // same-zone test (all_flux.jl:64-82): one boundary compare in the common case
   const bool fwd = p.x > p.x_old;
-  const double z_lo = S_x[p.i_grid], z_hi = S_x[p.i_grid + 1];       // both edges, no branch (one ds_read2)
-  const bool same_zone = (fwd & (z_hi > p.x)) | (!fwd & (z_lo <= p.x));
+  const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));   // the zone's edges are in registers
   // upward crossings that mean work: the end of the grid, the PRP (prob_return.jl:73,89) and the point
   // beyond which downstream_test ends the particle (x_dt, see refresh_dtest).  Five compares and four
   // scalar ops, no branch (a nested select compiles to exec-masked moves behind a 36-cycle skeleton).
@@ -924,6 +933,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
       }
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
+      load_zone_edges(p);
       if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) push_record(p, ig3);
     }
   }
@@ -989,6 +999,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     const int ig = p.i_grid, io = p.ig3;
     const bool etf_ev = h.etf && (f & F_CROSSED) && !p.inj && p.x_old <= 0 && p.i_grid_old != p.i_grid;
     p.ig3 = ig;
+    load_zone_props(p);
     double gd;
     if (h.custom_epsB && p.x > h.x_grid_stop) {
       const double bmag = S_bt[h.n_grid] * __builtin_sqrt(h.x_grid_stop / p.x);
@@ -1122,6 +1133,7 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
     p.i_grid = cand;
     push_record(p, p.ig3, (int)stack_height);
     p.ig3 = cand;
+    load_zone_props(p); load_zone_edges(p);
   }
   (void)m_ok;
   return ok;
@@ -1214,6 +1226,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   p.weight = 0; p.ptot_pf = 1; p.pb_pf = 0; p.p_perp = 1; p.gam_pf = 1; p.x = 0; p.x_old = 0; p.phi = 0; p.prp = 0; p.acctime = 0;
   p.xn_per = 1; p.dphi = 0; p.gyro_denom = 0; p.gyro_rad = 0; p.gyro_rad_tot = 0; p.gyro_period = 0; p.t_step = 0;
   p.rp_val = 1; p.cm_val = 1; p.rg_val = 1; p.x_dt = 0; p.t_ev = 0; p.flags = 0; p.ovr_inc = 0; p.n_ovr = 0u;
+  p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0;
   p.i_grid = 0; p.i_grid_old = 0; p.ig3 = 0; p.helix = 0; p.tcut = 1; p.n_retro = 0; p.downstream = false; p.inj = false;
   rng.init(0ull);
   bool active = false, exhausted = false;
@@ -1332,7 +1345,7 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
     if (!h.dont_scatter) scattering(rng, p, kc);
     {
       const bool ds = p.downstream;
-      const double acc_new = p.acctime + t_clock * S_gef[p.ig3];
+      const double acc_new = p.acctime + t_clock * p.z_gef;
       p.acctime = ds ? acc_new : p.acctime;
       p.n_ovr += (unsigned)p.ovr_inc;
       const bool ev_time = ds && p.acctime >= p.t_ev;
