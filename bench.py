@@ -167,7 +167,7 @@ def main():
                        "parallelism": f"particle shards x{world}, all-gather(n_saved)/pcut, all-reduce(tallies)/iter"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "mcs_k_transport", "launches": n_launch,
+                         "kernel": "mcs_k_transport_plain (the specialisation of mcs_k_transport for this configuration)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                          "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "

@@ -17,7 +17,7 @@
 extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
-hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st);
+hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
                                unsigned int* block_counts, unsigned long long* block_offsets,
                                unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st);
@@ -84,6 +84,8 @@ struct mcs_ctx {
   int i_iter = 1, i_ion = 1;
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
   bool have_grid = false, have_cuts = false;
+  bool all_parallel = false;   // theta == 0 in every zone (mcs_set_grid)
+  bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
   // consumers (K4): table staging, outputs, thermo scratch slab
   double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
   // launch
@@ -215,6 +217,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   if (device < 0 || device >= ndev) return fail("mcs_create: device ordinal out of range");
   HIPCHK(hipSetDevice(device));
   mcs_ctx* c = new mcs_ctx();
+  { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
   c->device = device;
@@ -310,6 +313,8 @@ int mcs_set_grid(mcs_ctx* c, int n_entries, const double* x_grid_cm, const doubl
   c->tb.x_grid = c->d_tab; c->tb.ux = c->d_tab + ne; c->tb.uz = c->d_tab + 2 * ne; c->tb.utot = c->d_tab + 3 * ne;
   c->tb.gsf = c->d_tab + 4 * ne; c->tb.gef = c->d_tab + 5 * ne; c->tb.btot = c->d_tab + 6 * ne; c->tb.theta = c->d_tab + 7 * ne;
   c->h_ux.assign(ux, ux + ne);
+  c->all_parallel = true;
+  for (int i = 0; i < ne; ++i) if (theta[i] != 0.0) c->all_parallel = false;
   c->have_grid = true;
   return 0;
 }
@@ -515,7 +520,11 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   }
   HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  if (n > 0) HIPCHK(mcs_launch_transport(c->d_args, c->P.n_grid, c->tb.n_tcuts, blocks, threads, c->stream));
+  // the specialised kernel for the common configuration (see transport_body<PLAIN> in mcs_transport.hip)
+  const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
+                     !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
+                     c->tb.n_xspec == 0 && !(a.inj_frac < 1);
+  if (n > 0) HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   unsigned long long ns = 0;
   HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));

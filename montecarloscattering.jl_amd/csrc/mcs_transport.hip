@@ -1159,8 +1159,12 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
   if (lane == 0) S_evcur[wv] = cnt;
 }
 
-extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD)
-mcs_k_transport(const KArgs* __restrict__ ka) {
+// PLAIN = the common configuration, decided by the host: scattering on, parallel field in every zone,
+// no custom eps_B, no energy transfer, no electron radiative losses, no downstream FEB, DSA on with
+// injection probability 1, ions, no x_spec detectors.  The flags are then compile-time constants: their
+// scalar branches and the code behind them disappear from that kernel.
+template <bool PLAIN>
+__device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
   Lds s;
@@ -1207,6 +1211,10 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   }
   h.every_pass = h.custom_epsB || (h.rad_losses && h.aa < 1) || h.dont_scatter;
   h.odd_cfg = h.feb_down > 0 || h.dont_DSA || h.inj_frac < 1 || h.aa < 1 || h.n_xspec != 0;
+  if (PLAIN) {
+    h.custom_epsB = false; h.etf = false; h.dont_scatter = false; h.dont_DSA = false; h.oblique = false;
+    h.every_pass = false; h.odd_cfg = false;
+  }
 
   // the 29 constants of the per-step sincos + asin, resident in VGPRs
   mcsm::HotCoef kc;
@@ -1390,6 +1398,13 @@ mcs_k_transport(const KArgs* __restrict__ ka) {
   }
 }
 
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport(const KArgs* __restrict__ ka) {
+  transport_body<false>(ka);
+}
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain(const KArgs* __restrict__ ka) {
+  transport_body<true>(ka);
+}
+
 #ifdef MCS_PROF
 extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * MCS_NPROF) != hipSuccess) return 1;
@@ -1401,8 +1416,9 @@ extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_gr
 extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 
 // `a_dev`: device copy of the launch constants (written by the caller on `st`).
-extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int n_grid, int n_tcuts, int blocks, int threads, hipStream_t st) {
-  (void)n_grid; (void)n_tcuts;
-  hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
+// `plain`: the host has checked the conditions of the PLAIN specialisation (see transport_body).
+extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st) {
+  if (plain) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
   return hipGetLastError();
 }

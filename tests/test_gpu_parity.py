@@ -204,6 +204,33 @@ def test_edge_cases_and_errors():
     hb.destroy()
 
 
+def test_specialised_and_general_kernel_agree(monkeypatch):
+    """The common configuration runs mcs_k_transport_plain (compile-time flags); MCS_FORCE_GENERAL=1 keeps
+    the general kernel.  Same problem through both: identical particles, identical integer tallies."""
+    N = 4000
+    prob = make_problem(N)
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MCS_FORCE_GENERAL", force)
+        hb = hip_backend(prob)
+        start_species(hb, prob)
+        fin = []
+        for ip in range(1, 10):
+            ns = hb.run_pcut(ip, 0)
+            fin.append((hb.finals(), hb.get_saved()))
+            hb.new_pcut(max(N // ns, 1))
+        out.append((fin, hb.read_tallies()))
+        hb.destroy()
+    (fa, (Ta, Ia)), (fb, (Tb, Ib)) = out
+    for (xa, (sa, la)), (xb, (sb, lb)) in zip(fa, fb):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), k
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, "saved arrays, plain vs general kernel")
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
+
+
 def test_results_do_not_depend_on_launch_geometry():
     """Which lane runs which particle is irrelevant: few blocks (lanes are refilled many
     times) and the automatic geometry give bit-identical particles."""
