@@ -108,8 +108,11 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
 }
 
 __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
-  const unsigned long long u = ((unsigned long long)hi << 32) | lo;
-  return (double)(u >> 11) * 0x1.0p-53;
+  // (double)(u64 >> 11) * 2^-53, spelled so that it costs 5 instructions: the 53-bit integer is
+  // h * 2^32 + l with h < 2^21; both conversions, the fma and the scaling are exact.
+  const uint32_t h = hi >> 11;
+  const uint32_t l = (hi << 21) | (lo >> 11);
+  return __builtin_ldexp(__builtin_fma((double)h, 4294967296.0, (double)l), -53);
 }
 
 // Per-particle stream: draw j -> words (2*(j&1), 2*(j&1)+1) of block j>>1.  The odd
@@ -1288,11 +1291,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     }
     double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
     // ---- the one rare region (see the comment above move_and_detect)
-    const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
+    // (ev and ev_x are false for a particle that has not moved yet; F_NEARFEB is one of the flags)
     const bool unusual = p.flags != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass;
-    PROF_LANES(13, active && (post_pending || unusual));
-    if (MCS_UNLIKELY(active && (post_pending || unusual))) {
+    PROF_LANES(13, active && (ev || ev_x || unusual));
+    if (MCS_UNLIKELY(active && (ev || ev_x || unusual))) {
       PROF_ADD(12, 1);
+      const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
       int end = -1;
       bool full = unusual || ev || h.etf || h.custom_epsB;
       if (!full) full = !plain_crossing(a, h, p, ev_pending);
