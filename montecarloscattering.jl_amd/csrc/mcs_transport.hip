@@ -40,6 +40,9 @@
 #ifndef MCS_WAVES_PER_SIMD
 #define MCS_WAVES_PER_SIMD 2
 #endif
+#ifndef MCS_REFILL_MIN
+#define MCS_REFILL_MIN 8        // idle lanes a wave collects before it claims new particles (measured: 1 -> 630 ms, 2 -> 617, 4 -> 615, 8 -> 610, 16 -> 611)
+#endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
 // calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
 #ifdef MCS_INLINE_COLD
@@ -1257,11 +1260,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     p.npush = 0;
     // ---- housekeeping behind ONE scalar branch: records to tally, idle lanes to refill, nothing left
     const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
-    if (MCS_UNLIKELY(ev_pending >= 64u || (act_mask != ~0ull && !exhausted) || act_mask == 0ull)) {
+    // Refills are batched: a load of new particles stalls the whole wave for a memory latency (about one
+    // pass), so the wave waits until MCS_REFILL_MIN lanes are idle.  With histories of a few hundred
+    // passes (late pcuts) a lane idles every 3-4 passes and refilling each at once cost ~25 % of the time.
+    const int n_idle = 64 - __popcll(act_mask);
+    if (MCS_UNLIKELY(ev_pending >= 64u || (n_idle >= MCS_REFILL_MIN && !exhausted) || act_mask == 0ull)) {
       if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
       // refill idle lanes (wave-aggregated claim)
       const unsigned long long idle = ~act_mask;
-      if (idle != 0ull && !exhausted) {
+      if (n_idle >= MCS_REFILL_MIN && !exhausted) {
         const int nidle = __popcll(idle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned long long base = 0;
