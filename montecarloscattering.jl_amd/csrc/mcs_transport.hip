@@ -244,6 +244,7 @@ __shared__ unsigned long long S_steps[3];   // helix steps, retro steps, RNG dra
 #ifdef MCS_PROF
 #define MCS_NPROF 32
 __device__ unsigned long long g_prof[MCS_NPROF];
+__device__ unsigned long long g_wave[8192][4];   // per wave: start, counter exhausted, end (s_memrealtime, 100 MHz), live lanes at exhaustion (tools/gpu_timeline.py)
 __shared__ unsigned long long S_prof[MCS_NPROF];
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(slot, v) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)(v)); } while (0)
@@ -1253,6 +1254,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const unsigned long long n = (unsigned long long)a->n;
 
   const unsigned wv = threadIdx.x >> 6;
+#ifdef MCS_PROF
+  const unsigned gw__ = (blockIdx.x * 4u + wv) & 8191u;
+  if (lane == 0) { g_wave[gw__][0] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][1] = 0; }
+#endif
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.npush = 0;
   for (;;) {
@@ -1276,6 +1281,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         base = __shfl(base, leader);
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
+#ifdef MCS_PROF
+          if (lane == 0 && g_wave[gw__][1] == 0) { g_wave[gw__][1] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][3] = (unsigned long long)__popcll(act_mask); }
+#endif
         } else if (!active) {
           const int rank = __popcll(idle & ((1ull << lane) - 1ull));
           const unsigned long long idx = base + (unsigned long long)rank;
@@ -1373,6 +1381,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     moved = true;
   }
 
+#ifdef MCS_PROF
+  if (lane == 0) g_wave[gw__][2] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- the wave's remaining tally records, then the LDS staging
   drain_events(a, s, wv, lane, true);
   __syncthreads();
@@ -1417,6 +1428,9 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 }
 
 #ifdef MCS_PROF
+extern "C" int mcs_prof_waves(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave), sizeof(unsigned long long) * 8192 * 4) != hipSuccess;
+}
 extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * MCS_NPROF) != hipSuccess) return 1;
   if (reset) { unsigned long long z[MCS_NPROF] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1; }
