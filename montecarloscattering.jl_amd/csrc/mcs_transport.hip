@@ -8,19 +8,24 @@
 // (src/prob_return.jl:36-344), tcut_track! (src/cuts.jl:149-162) and
 // particle_finish! (src/particle_finish.jl:46-107).
 //
-// Execution model (CDNA4):
+// Execution model (CDNA4; the measurements behind it are in DESIGN.md section 4 and profiles/):
 //  * one wavefront lane = one live particle; all particle state lives in VGPRs;
 //  * persistent lanes: a lane whose particle finished claims the next unclaimed
-//    particle (wave-aggregated atomic on one counter), so the 64 lanes of a wave
-//    stay busy although histories last 1 .. 10^4 steps;
+//    particle (wave-aggregated atomic on one counter, 8 idle lanes at a time), so the
+//    64 lanes of a wave stay busy although histories last 1 .. 10^4 passes;
+//  * flag-driven loop: the common pass (scatter, clock, move, event detection) is
+//    straight-line code that EVERY lane executes; everything rare -- before or after
+//    the move -- sits in one region entered when the lane has an event pending or a
+//    bit set in its flags register (see the comment above move_and_detect);
 //  * the grid tables (n_grid+2 fp64 each) plus per-zone sin/cos(theta_B) and
-//    1/(qB), and the time cuts, sit in LDS; the three flux vectors and
-//    num_crossings are staged in LDS (ds_add_f64) and flushed with one global atomic
-//    per entry per block; the 22 MB psd and the escape spectra take
-//    global_atomic_add_f64 (no-return) directly;
-//  * the hot loop issues NO global load and NO scratch access: the vmcnt queue
-//    holds only no-return atomics, which nothing waits for;
-//  * launch constants are read through the constant address space (s_load);
+//    1/(qB), and the time cuts, sit in LDS (the current zone's values in registers);
+//    zone-crossing tallies are pushed as records onto per-wave LDS stacks and tallied
+//    64 at a time; the three flux vectors, num_crossings and the counters are staged
+//    in LDS (ds_add_f64) and flushed with one global atomic per entry per block; the
+//    22 MB psd and the escape spectra take global_atomic_add_f64 (no-return);
+//  * the common pass issues NO global load, NO LDS table read and NO scratch access;
+//  * two kernels from this source: mcs_k_transport and its compile-time
+//    specialisation for the common configuration, mcs_k_transport_plain;
 //  * RNG: Philox4x32-10 keyed by the reference's iseed_mod, counter = draw
 //    number; no RNG state in memory;
 //  * no MFMA: scalar fp64 per-particle arithmetic.
