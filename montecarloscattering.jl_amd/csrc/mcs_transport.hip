@@ -748,11 +748,17 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
   }
 }
 
+// (the explicit s_waitcnt lgkmcnt(0) keeps the wait for these LDS reads here, in rare code; otherwise the
+// compiler waits at the first use, which is in the common pass -- four s_waitcnt per pass for nothing)
 __device__ __forceinline__ void load_zone_props(Pt& p) {
   const int z = p.ig3;
   p.z_gsf = S_gsf[z]; p.z_bcos = S_bcos[z]; p.z_ux = S_ux[z]; p.z_gef = S_gef[z];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 }
-__device__ __forceinline__ void load_zone_edges(Pt& p) { p.z_lo = S_x[p.i_grid]; p.z_hi = S_x[p.i_grid + 1]; }
+__device__ __forceinline__ void load_zone_edges(Pt& p) {
+  p.z_lo = S_x[p.i_grid]; p.z_hi = S_x[p.i_grid + 1];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+}
 
 // load a particle and run the prologue of particle_loop (src/particle_loop.jl:44-153)
 __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h, long long k, Pt& p, Rng& rng) {
@@ -1296,6 +1302,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             k = (long long)idx;
             load_particle(a, s, h, k, p, rng);
             active = true; ev = false; ev_x = false; moved = false;
+            // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
+            // every outstanding store and no-return tally atomic)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
           }
         }
         PROF_ADD(5, 1); PROF_ADD(6, nidle);
