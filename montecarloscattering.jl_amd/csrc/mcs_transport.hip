@@ -1121,15 +1121,15 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
 __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsigned stack_height) {
   const int ne = h.n_grid + 2;
   const bool fwd = p.x > p.x_old;
-  // neighbour first -- its far edge, flow speed and field in ONE round of LDS reads; the zone search
-  // of all_flux! (all_flux.jl:68-72) stops there iff that edge is beyond x.  All tests feed one
+  // neighbour first: its edges, flow speed, field and the other zone properties in ONE round of LDS
+  // reads (the same values become the cached zone properties on success); the zone search of all_flux!
+  // (all_flux.jl:68-72) stops at the neighbour iff its far edge is beyond x.  All tests feed one
   // predicate: no early return, one conditional region for the commit.
   int cand = fwd ? p.i_grid + 1 : p.i_grid - 1;
   cand = cand < 0 ? 0 : (cand > ne - 2 ? ne - 2 : cand);
-  const double far = fwd ? S_x[cand + 1] : S_x[cand];
-  double ux_c = S_ux[cand], gd_c = S_gd[cand];
-  const double ux_3 = S_ux[p.ig3];
-  const bool adjacent = (fwd ? far > p.x : far <= p.x) && cand != p.i_grid;
+  double c_lo = S_x[cand], c_hi = S_x[cand + 1];
+  double ux_c = S_ux[cand], gd_c = S_gd[cand], gsf_c = S_gsf[cand], bcos_c = S_bcos[cand], gef_c = S_gef[cand];
+  const bool adjacent = (fwd ? c_hi > p.x : c_lo <= p.x) && cand != p.i_grid;
   const bool shock = p.x_old < 0 && p.x >= 0;
   if (MCS_UNLIKELY(!adjacent && !shock)) {
     // one step can cross several of the thin zones near the shock: the search loop
@@ -1140,20 +1140,18 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
       for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
     }
     const int c = cand < 0 ? 0 : cand;
-    ux_c = S_ux[c]; gd_c = S_gd[c];
+    c_lo = S_x[c]; c_hi = S_x[c + 1];
+    ux_c = S_ux[c]; gd_c = S_gd[c]; gsf_c = S_gsf[c]; bcos_c = S_bcos[c]; gef_c = S_gef[c];
   }
-  const bool ok = !shock && cand >= 0 && cand > h.i_grid_feb && ux_c == ux_3 && gd_c == p.gyro_denom;
-  // the first push site of a pass: every lane that pushes here is in this call together
-  const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
+  const bool ok = !shock && cand >= 0 && cand > h.i_grid_feb && ux_c == p.z_ux && gd_c == p.gyro_denom;
   if (ok) {
     if (p.downstream && p.x < 0) p.inj = true;
     p.i_grid_old = p.i_grid;
     p.i_grid = cand;
-    push_record(p, p.ig3, (int)stack_height);
+    push_record(p, p.ig3, (int)stack_height);     // the first push site of a pass: the height is the register mirror
     p.ig3 = cand;
-    load_zone_props(p); load_zone_edges(p);
+    p.z_lo = c_lo; p.z_hi = c_hi; p.z_gsf = gsf_c; p.z_bcos = bcos_c; p.z_ux = ux_c; p.z_gef = gef_c;
   }
-  (void)m_ok;
   return ok;
 }
 
