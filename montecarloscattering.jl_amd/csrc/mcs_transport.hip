@@ -249,7 +249,7 @@ __shared__ unsigned long long S_steps[3];   // helix steps, retro steps, RNG dra
 #ifdef MCS_PROF
 #define MCS_NPROF 32
 __device__ unsigned long long g_prof[MCS_NPROF];
-__device__ unsigned long long g_wave[8192][4];   // per wave: start, counter exhausted, end (s_memrealtime, 100 MHz), live lanes at exhaustion (tools/gpu_timeline.py)
+__device__ unsigned long long g_wave[8192][8];   // per wave: start, counter exhausted, end (s_memrealtime, 100 MHz), live lanes at exhaustion (tools/gpu_timeline.py)
 __shared__ unsigned long long S_prof[MCS_NPROF];
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(slot, v) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)(v)); } while (0)
@@ -1266,6 +1266,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF
   const unsigned gw__ = (blockIdx.x * 4u + wv) & 8191u;
   if (lane == 0) { g_wave[gw__][0] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][1] = 0; }
+  unsigned long long xp__ = 0, xr__ = 0, xl__ = 0, xf__ = 0;   // after exhaustion: passes, rare entries, live-lane sum, full-path lanes
 #endif
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.npush = 0;
@@ -1315,6 +1316,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     {
       [[maybe_unused]] const int na__ = __popcll(__builtin_amdgcn_ballot_w64(active));
       PROF_ADD(0, 1); PROF_ADD(8, na__);
+#ifdef MCS_PROF
+      if (exhausted) { xp__ += 1; xl__ += (unsigned long long)na__; }
+#endif
     }
     double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
     // ---- the one rare region (see the comment above move_and_detect)
@@ -1329,6 +1333,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       if (!full) full = !plain_crossing(a, h, p, ev_pending);
       PROF_LANES(16, full);
 #ifdef MCS_PROF
+      if (exhausted) { xr__ += 1; xf__ += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(full)); }
       {
         const double xup__ = p.x_old < h.x_grid_stop ? h.x_grid_stop : (p.x_old < p.prp ? p.prp : p.x_dt);
         PROF_LANES(22, moved && ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse)));
@@ -1394,7 +1399,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   }
 
 #ifdef MCS_PROF
-  if (lane == 0) g_wave[gw__][2] = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) { g_wave[gw__][2] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][4] = xp__; g_wave[gw__][6] = xl__;
+    g_wave[gw__][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
+    g_wave[gw__][7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); }   // HW_REG_XCC_ID
 #endif
   // ---- the wave's remaining tally records, then the LDS staging
   drain_events(a, s, wv, lane, true);
@@ -1441,7 +1448,7 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave), sizeof(unsigned long long) * 8192 * 4) != hipSuccess;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave), sizeof(unsigned long long) * 8192 * 8) != hipSuccess;
 }
 extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * MCS_NPROF) != hipSuccess) return 1;
