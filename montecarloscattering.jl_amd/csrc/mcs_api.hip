@@ -85,6 +85,7 @@ struct mcs_ctx {
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
   bool have_grid = false, have_cuts = false;
   bool all_parallel = false;   // theta == 0 in every zone (mcs_set_grid)
+  bool tail_merge = true;      // MCS_TAIL_MERGE=0: no consolidation of sparse waves (A/B measurements)
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
   // consumers (K4): table staging, outputs, thermo scratch slab
   double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
@@ -218,6 +219,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipSetDevice(device));
   mcs_ctx* c = new mcs_ctx();
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
+  { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
   c->device = device;
@@ -507,6 +509,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
                                      (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
                                      (long long)(i_pcut - 1) * c->P.n_pts_max);
   a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
+  a.tail_merge = c->tail_merge ? 1 : 0;
   a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
 
   const int threads = c->threads;

@@ -46,6 +46,7 @@ struct KArgs {
   unsigned long long* n_saved;
   int32_t *f_reason, *f_helix, *f_retro;
   double *f_ptot, *f_x;
+  int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
 };
 
 // zone-crossing tally records staged in LDS by the transport kernel

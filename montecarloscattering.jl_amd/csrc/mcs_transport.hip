@@ -198,6 +198,7 @@ struct Lds {                                // kept as an (empty) handle so call
 #define F_SAVE    0x040   // downstream && ptot_pf > pcut: saved for the next pcut at the next Code Block 3
 #define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
 #define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
+#define F_CM      0x200   // only cos_max is stale (fine/coarse switch in the last pass): refresh_scatter alone
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double dphi;                   // 2pi / xn_per (particle_loop.jl:529)
@@ -247,17 +248,31 @@ __shared__ unsigned long long S_steps[3];   // helix steps, retro steps, RNG dra
 
 // ---- optional phase profile (-DMCS_PROF; tools/gpu_prof.py): cycle / lane counts per loop phase
 #ifdef MCS_PROF
-#define MCS_NPROF 32
+#define MCS_NPROF 64
 __device__ unsigned long long g_prof[MCS_NPROF];
 __device__ unsigned long long g_wave[8192][8];   // per wave: start, counter exhausted, end (s_memrealtime, 100 MHz), live lanes at exhaustion (tools/gpu_timeline.py)
 __shared__ unsigned long long S_prof[MCS_NPROF];
 #define PROF_T() __builtin_amdgcn_s_memtime()
-#define PROF_ADD(slot, v) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)(v)); } while (0)
-#define PROF_LANES(slot, pred) do { const unsigned long long m__ = __ballot(pred); if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)__popcll(m__)); } while (0)
+#ifdef MCS_PROF_TAIL   // count only the passes after the work counter is exhausted
+#define PROF_GATE exhausted
+__shared__ unsigned int S_ttgate[4];            // 1 once this wave found the work counter exhausted
+__shared__ unsigned long long S_tttm[4];        // time of the last mark of this wave
+#define TTG_START() do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) S_tttm[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TTG_MARK(slot) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); \
+    if (S_ttgate[threadIdx.x >> 6]) { atomicAdd(&S_prof[slot], tn__ - S_tttm[threadIdx.x >> 6]); atomicAdd(&S_prof[(slot) + 8], 1ull); } S_tttm[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PROF_GATE true
+#endif
+#define PROF_ADD(slot, v) do { if (PROF_GATE && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)(v)); } while (0)
+#define PROF_LANES(slot, pred) do { const unsigned long long m__ = __ballot(pred); if (PROF_GATE && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], (unsigned long long)__popcll(m__)); } while (0)
 #else
 #define PROF_T() 0ull
 #define PROF_ADD(slot, v) do { } while (0)
 #define PROF_LANES(slot, pred) do { } while (0)
+#endif
+#ifndef MCS_PROF_TAIL
+#define TTG_START() do { } while (0)
+#define TTG_MARK(slot) do { } while (0)
 #endif
 __device__ __forceinline__ void cnt(CK* a, int which, unsigned int v = 1u) {
   (void)a;
@@ -544,6 +559,9 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
   const double mc = aa * MP_ * CC_;
   while (true) {
     ++r.n_retro;
+#ifdef MCS_PROF_TAIL
+    if (S_ttgate[threadIdx.x >> 6]) atomicAdd(&S_prof[39], 1ull);
+#endif
     const double x_PT_old = x_PT;
     const double phi_old = r.phi;
     if (P.use_custom_epsB) {
@@ -799,6 +817,34 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.npush = 0;
 }
 
+// The zone search of all_flux! (src/all_flux.jl:68-72): forward, `findnext(>(x), x_grid, i+1) - 1` -- the first
+// j >= i_grid+1 with x_grid[j] > x, minus one; backward, `findprev(<=(x), x_grid, i)` -- the first j <= i_grid,
+// going down, with x_grid[j] <= x; -1 when the scan runs off the grid.  `skip` leading candidates are known to
+// fail.  A linear scan costs one LDS round trip (~170 cycles of a lone wave) per zone, and one move of an
+// energetic particle crosses dozens of the thin zones near the shock: three candidates are probed in one round,
+// the rest is a binary search (the grid is strictly increasing, checked by mcs_set_grid) -- same result.
+__device__ __forceinline__ int zone_search(double x, bool fwd, int i_grid, int ne, int skip) {
+  const int st = fwd ? 1 : -1;
+  const int a0 = fwd ? i_grid + 1 + skip : i_grid - skip, a1 = a0 + st, a2 = a1 + st;
+  const int c0 = a0 < 0 ? 0 : (a0 > ne - 1 ? ne - 1 : a0), c1 = a1 < 0 ? 0 : (a1 > ne - 1 ? ne - 1 : a1),
+            c2 = a2 < 0 ? 0 : (a2 > ne - 1 ? ne - 1 : a2);
+  const double v0 = S_x[c0], v1 = S_x[c1], v2 = S_x[c2];
+  const bool h0 = fwd ? v0 > x : v0 <= x, h1 = fwd ? v1 > x : v1 <= x, h2 = fwd ? v2 > x : v2 <= x;
+  if (a0 != c0) return -1;
+  if (h0) return fwd ? a0 - 1 : a0;
+  if (a1 != c1) return -1;
+  if (h1) return fwd ? a1 - 1 : a1;
+  if (a2 != c2) return -1;
+  if (h2) return fwd ? a2 - 1 : a2;
+  // first g in [lo, hi) with x_grid[g] > x
+  int lo = fwd ? a2 + 1 : 0, hi = fwd ? ne : a2;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (S_x[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  return (fwd && lo >= ne) ? -1 : lo - 1;
+}
+
 // Zone-crossing tallies do not feed back into the particle: the lane pushes a record on its wave's
 // LDS stack (see S_evf) instead of tallying on the spot.  The stack cannot overflow: it is drained
 // to < 64 at the top of every pass and one pass adds at most two records per lane -- one for the move
@@ -909,6 +955,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
     tcut_track(a, p.tcut, p.weight, p.ptot_pf);
     p.tcut += 1;
   }
+  TTG_MARK(40);
   const bool ev_reflect = p.x <= 0 && p.x_old > 0 && !p.inj && (h.dont_DSA || h.inj_frac < 1);
   const bool ev_shock = p.x_old < 0 && p.x >= 0;
   if (!ev_shock && !ev_reflect && p.downstream && p.x < 0) p.inj = true;   // particle_loop.jl:433-435
@@ -937,24 +984,20 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
     }
     if (p.downstream && p.x < 0) p.inj = true;
   }
+  TTG_MARK(41);
   {
     // all_flux! (all_flux.jl:45-82): zone search; a tally record only when something was crossed
     const bool fwd = p.x > p.x_old;
     const bool same_zone = fwd ? (S_x[p.i_grid + 1] > p.x) : (S_x[p.i_grid] <= p.x);
     if (!same_zone || p.i_grid <= h.i_grid_feb || h.n_xspec != 0 || ev_reflect) {
-      const int ne = h.n_grid + 2;
-      int found = -1;
-      if (fwd) {
-        for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { found = j - 1; break; }
-      } else {
-        for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { found = j; break; }
-      }
+      const int found = zone_search(p.x, fwd, p.i_grid, h.n_grid + 2, 0);
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
       load_zone_edges(p);
       if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) push_record(p, ig3);
     }
   }
+  TTG_MARK(42);
   // downstream_test (particle_loop.jl:595-637) and prob_return, from scratch
   int i_return = 2;                              // prob_return's default (prob_return.jl:48)
   bool do_prob_ret = true;
@@ -973,7 +1016,9 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
     if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; }
   }
   bool lose_pt = false;
+  TTG_MARK(43);
   if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt);
+  TTG_MARK(44);
   if (i_return == 0) {
     double vel = p.ptot_pf / h.m;
     if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
@@ -990,6 +1035,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
   p.flags = f;
   refresh_time(a, h, p);
   refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
+  TTG_MARK(45);
   return -1;
 }
 
@@ -1070,13 +1116,16 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
     p.flags |= F_RS | F_RM;
   }
-  if (p.flags & F_RS) {
+  if (p.flags & (F_RS | F_CM)) {
     if (!h.dont_scatter) refresh_scatter(a, p, aa, aa * MP_ * CC_, h.eta);   // with the OLD xn_per, as the reference
-    refresh_dtest(a, h, p);
-    int g = p.flags & ~(F_RS | F_NEARP | F_SAVE);
-    if (p.ptot_pf > h.pmax_cutoff) g |= F_NEARP;
-    if (p.downstream && p.ptot_pf > h.pcut) g |= F_SAVE;
-    p.flags = g;
+    if (p.flags & F_RS) {
+      refresh_dtest(a, h, p);
+      int g = p.flags & ~(F_RS | F_NEARP | F_SAVE);
+      if (p.ptot_pf > h.pmax_cutoff) g |= F_NEARP;
+      if (p.downstream && p.ptot_pf > h.pcut) g |= F_SAVE;
+      p.flags = g;
+    }
+    p.flags &= ~F_CM;
   }
   if (p.flags & F_SAVE) {
     // saved for the next pcut (particle_loop.jl:361-380): scatter, clock, time cut -- no move
@@ -1094,7 +1143,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
   // reference -- the scatter touches neither x nor gyro_rad_tot.  cos_max keeps the old xn_per for
   // the coming scatter and is refreshed for the one after (F_RS), exactly as in the reference.
   const double xn = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
-  if (xn != p.xn_per) { p.xn_per = xn; p.flags |= F_RS | F_RM; }
+  if (xn != p.xn_per) { p.xn_per = xn; p.flags |= F_CM | F_RM; }   // x_dt, F_NEARP, F_SAVE do not depend on xn_per
   if (p.flags & F_RM) refresh_move(a, h, p);
   return -1;
 }
@@ -1133,12 +1182,8 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
   const bool shock = p.x_old < 0 && p.x >= 0;
   if (MCS_UNLIKELY(!adjacent && !shock)) {
     // one step can cross several of the thin zones near the shock: the search loop
-    cand = -1;
-    if (fwd) {
-      for (int j = p.i_grid + 1; j < ne; ++j) if (S_x[j] > p.x) { cand = j - 1; break; }
-    } else {
-      for (int j = p.i_grid; j >= 0; --j) if (S_x[j] <= p.x) { cand = j; break; }
-    }
+    // (the zone's own edge and the neighbour's far edge are known to fail: two candidates skipped)
+    cand = zone_search(p.x, fwd, p.i_grid, ne, 2);
     const int c = cand < 0 ? 0 : cand;
     c_lo = S_x[c]; c_hi = S_x[c + 1];
     ux_c = S_ux[c]; gd_c = S_gd[c]; gsf_c = S_gsf[c]; bcos_c = S_bcos[c]; gef_c = S_gef[c];
@@ -1175,6 +1220,67 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
   if (lane == 0) S_evcur[wv] = cnt;
 }
 
+// ---- tail consolidation: two sparse waves of a block become one ---------------------------------
+// After the work counter is exhausted no lane is refilled and a wave decays from ~56 live lanes to the one
+// longest history; a pass costs the same with 1 live lane as with 64, and the two waves that share a SIMD
+// (one of each of the CU's two blocks) split its issue slots: 1.4 us per pass each instead of 0.8 us alone
+// (profiles/r01_wave_timeline.txt).  So the waves of a block pair up by SIMD, (0,1) and (2,3): once the
+// donor's live particles fit into the receiver's idle lanes the donor drains its tally records, writes the
+// complete lane state of its particles into its (now free) record stack, hands it over and ends; the
+// receiver picks the particles up at its next poll (every 16 passes).  Which wave of a pair stays is
+// chosen by the wave-slot id, which differs between the two blocks resident on a CU (measured: all waves
+// of a block share it), so that the surviving waves of both blocks sit on different SIMDs.  A history does
+// not depend on the lane that runs it (state and RNG stream travel with the particle): results unchanged.
+// Nobody ever waits: a state word per pair (open -> donated -> closed | open -> closed) is moved by CAS.
+#define MCS_MB_SLOTS 32
+#define MCS_MB_WORDS 36
+static_assert(MCS_MB_WORDS * MCS_MB_SLOTS <= MCS_EV_F64 * MCS_EV_CAP, "the mailbox lives in the donor's record stack");
+__shared__ unsigned int S_msimd[4];     // SIMD id of each wave (HW_REG_HW_ID[5:4])
+__shared__ unsigned int S_mlive[4];     // live lanes an exhausted receiver last published (64 before that)
+__shared__ unsigned int S_mstate[2];    // per SIMD pair: 0 open, 1 donated, 2 closed
+__shared__ unsigned int S_mcount[2];    // particles in the mailbox
+
+__device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x,
+                                         bool moved, double phi_prev) {
+  double* mb = &S_evf[box][0][0] + r;
+  const double v[30] = {p.weight, p.ptot_pf, p.pb_pf, p.p_perp, p.gam_pf, p.x, p.x_old, p.phi, p.prp, p.acctime, p.xn_per, p.dphi,
+                        p.gyro_denom, p.gyro_rad, p.gyro_rad_tot, p.gyro_period, p.t_step, p.rp_val, p.cm_val, p.rg_val, p.x_dt,
+                        p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, rng.spare, phi_prev};
+#pragma unroll
+  for (int j = 0; j < 30; ++j) mb[j * MCS_MB_SLOTS] = v[j];
+  mb[30 * MCS_MB_SLOTS] = __longlong_as_double(k);
+  const int gridpack = p.i_grid | (p.i_grid_old << 8) | (p.ig3 << 16) | (p.tcut << 24);
+  const int bits = p.ovr_inc | ((int)p.downstream << 1) | ((int)p.inj << 2) | ((int)ev << 3) | ((int)ev_x << 4) | ((int)moved << 5);
+  mb[31 * MCS_MB_SLOTS] = __hiloint2double(p.flags, (int)p.n_ovr);
+  mb[32 * MCS_MB_SLOTS] = __hiloint2double(gridpack, p.helix);
+  mb[33 * MCS_MB_SLOTS] = __hiloint2double(p.n_retro, bits);
+  mb[34 * MCS_MB_SLOTS] = __hiloint2double((int)rng.k0, (int)rng.k1);
+  mb[35 * MCS_MB_SLOTS] = __hiloint2double((int)rng.n, 0);
+}
+__device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
+                                        double& phi_prev) {
+  const double* mb = &S_evf[box][0][0] + r;
+  double* const d[30] = {&p.weight, &p.ptot_pf, &p.pb_pf, &p.p_perp, &p.gam_pf, &p.x, &p.x_old, &p.phi, &p.prp, &p.acctime, &p.xn_per,
+                         &p.dphi, &p.gyro_denom, &p.gyro_rad, &p.gyro_rad_tot, &p.gyro_period, &p.t_step, &p.rp_val, &p.cm_val,
+                         &p.rg_val, &p.x_dt, &p.t_ev, &p.z_gsf, &p.z_bcos, &p.z_ux, &p.z_gef, &p.z_lo, &p.z_hi, &rng.spare, &phi_prev};
+#pragma unroll
+  for (int j = 0; j < 30; ++j) *d[j] = mb[j * MCS_MB_SLOTS];
+  k = __double_as_longlong(mb[30 * MCS_MB_SLOTS]);
+  const double w1 = mb[31 * MCS_MB_SLOTS], w2 = mb[32 * MCS_MB_SLOTS], w3 = mb[33 * MCS_MB_SLOTS], w4 = mb[34 * MCS_MB_SLOTS],
+               w5 = mb[35 * MCS_MB_SLOTS];
+  p.flags = __double2hiint(w1); p.n_ovr = (unsigned)__double2loint(w1);
+  const int gridpack = __double2hiint(w2);
+  p.helix = __double2loint(w2);
+  p.i_grid = gridpack & 0xff; p.i_grid_old = (gridpack >> 8) & 0xff; p.ig3 = (gridpack >> 16) & 0xff; p.tcut = (gridpack >> 24) & 0xff;
+  p.n_retro = __double2hiint(w3);
+  const int bits = __double2loint(w3);
+  p.ovr_inc = bits & 1; p.downstream = (bits >> 1) & 1; p.inj = (bits >> 2) & 1; ev = (bits >> 3) & 1; ev_x = (bits >> 4) & 1;
+  moved = (bits >> 5) & 1;
+  rng.k0 = (uint32_t)__double2hiint(w4); rng.k1 = (uint32_t)__double2loint(w4);
+  rng.n = (uint32_t)__double2hiint(w5);
+  p.npush = 0;
+}
+
 // PLAIN = the common configuration, decided by the host: scattering on, parallel field in every zone,
 // no custom eps_B, no energy transfer, no electron radiative losses, no downstream FEB, DSA on with
 // injection probability 1, ions, no x_spec detectors.  The flags are then compile-time constants: their
@@ -1200,7 +1306,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
   if (threadIdx.x < 8) g_sc[threadIdx.x] = 0.0;
   if (threadIdx.x < 3) S_steps[threadIdx.x] = 0ull;
-  if (threadIdx.x < 4) S_evcur[threadIdx.x] = 0u;
+  if (threadIdx.x < 4) { S_evcur[threadIdx.x] = 0u; S_mlive[threadIdx.x] = 64u; }
+#ifdef MCS_PROF_TAIL
+  if (threadIdx.x < 4) S_ttgate[threadIdx.x] = 0u;
+#endif
+  if (threadIdx.x < 2) { S_mstate[threadIdx.x] = 0u; S_mcount[threadIdx.x] = 0u; }
+  if ((threadIdx.x & 63u) == 0u) S_msimd[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF) S_prof[threadIdx.x] = 0ull;
 #endif
@@ -1263,6 +1374,22 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const unsigned long long n = (unsigned long long)a->n;
 
   const unsigned wv = threadIdx.x >> 6;
+  // tail consolidation (see mb_store): role of this wave, decided once
+  int mrole = 0;                    // 0 none / done, 1 donor, 2 receiver
+  unsigned mpartner = 0, mpair = 0;
+  unsigned mtick = 0, mpoll_mask = ~0u;     // the poll happens when (mtick & mpoll_mask) == 0: never before exhaustion
+  if (blockDim.x == 256u && a->tail_merge) {
+    const unsigned s0 = S_msimd[0], s1 = S_msimd[1], s2 = S_msimd[2], s3 = S_msimd[3];
+    const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 15u;
+    const unsigned mine = S_msimd[wv], want = mine ^ 1u;
+    const unsigned partner = s0 == want ? 0u : (s1 == want ? 1u : (s2 == want ? 2u : 3u));
+    const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (__builtin_amdgcn_readfirstlane(distinct ? 1 : 0)) {
+      mpartner = (unsigned)__builtin_amdgcn_readfirstlane((int)partner);
+      mpair = (unsigned)__builtin_amdgcn_readfirstlane((int)(mine >> 1));
+      mrole = __builtin_amdgcn_readfirstlane((int)(((mine ^ slot) & 1u) == 0u ? 2 : 1));
+    }
+  }
 #ifdef MCS_PROF
   const unsigned gw__ = (blockIdx.x * 4u + wv) & 8191u;
   if (lane == 0) { g_wave[gw__][0] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][1] = 0; }
@@ -1279,7 +1406,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // pass), so the wave waits until MCS_REFILL_MIN lanes are idle.  With histories of a few hundred
     // passes (late pcuts) a lane idles every 3-4 passes and refilling each at once cost ~25 % of the time.
     const int n_idle = 64 - __popcll(act_mask);
-    if (MCS_UNLIKELY(ev_pending >= 64u || (n_idle >= MCS_REFILL_MIN && !exhausted) || act_mask == 0ull)) {
+    ++mtick;
+    if (MCS_UNLIKELY(ev_pending >= 64u || (n_idle >= MCS_REFILL_MIN && !exhausted) || act_mask == 0ull || (mtick & mpoll_mask) == 0u)) {
       if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
       // refill idle lanes (wave-aggregated claim)
       const unsigned long long idle = ~act_mask;
@@ -1291,6 +1419,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         base = __shfl(base, leader);
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
+          if (mrole != 0) mpoll_mask = 15u;
+#ifdef MCS_PROF_TAIL
+          if (lane == 0) S_ttgate[wv] = 1u;
+#endif
 #ifdef MCS_PROF
           if (lane == 0 && g_wave[gw__][1] == 0) { g_wave[gw__][1] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][3] = (unsigned long long)__popcll(act_mask); }
 #endif
@@ -1307,6 +1439,55 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           }
         }
         PROF_ADD(5, 1); PROF_ADD(6, nidle);
+      }
+      // ---- tail consolidation (see mb_store); `exhausted` holds whenever mpoll_mask is 15
+      const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      auto take_donation = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned cntm = (unsigned)__builtin_amdgcn_readfirstlane((int)S_mcount[mpair]);
+        const unsigned long long idle_now = ~__builtin_amdgcn_ballot_w64(active);
+        const unsigned r = (unsigned)__popcll(idle_now & lt_mask);
+        if (!active && r < cntm) {
+          mb_load(mpartner, r, p, rng, k, ev, ev_x, moved, phi_prev);
+          active = true;
+        }
+        mrole = 0; mpoll_mask = ~0u;
+      };
+      if (mrole != 0 && exhausted) {
+        const int nlive = __popcll(__builtin_amdgcn_ballot_w64(active));
+        if (mrole == 2) {
+          // receiver: publish the room (live lanes only decrease from now on), look for a donation; when it
+          // has nothing left it closes the pair -- unless the donation arrived first
+          unsigned st = 0u;
+          if (lane == 0) {
+            S_mlive[wv] = (unsigned)nlive;
+            st = nlive == 0 ? atomicCAS(&S_mstate[mpair], 0u, 2u) : __hip_atomic_load(&S_mstate[mpair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
+          if (st == 1u) {
+            take_donation();
+            if (lane == 0) S_mstate[mpair] = 2u;
+          } else if (st == 2u || nlive == 0) { mrole = 0; mpoll_mask = ~0u; }
+        } else {
+          const int room = 64 - (int)__builtin_amdgcn_readfirstlane((int)S_mlive[mpartner]);
+          if (nlive == 0) {
+            if (lane == 0) (void)atomicCAS(&S_mstate[mpair], 0u, 2u);     // nothing to give: the receiver stops polling
+            mrole = 0; mpoll_mask = ~0u;
+          } else if (nlive <= MCS_MB_SLOTS && nlive <= room) {
+            // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
+            drain_events(a, s, wv, lane, true); ev_pending = 0u;
+            if (active) mb_store(wv, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active) & lt_mask), p, rng, k, ev, ev_x, moved, phi_prev);
+            unsigned st = 2u;
+            if (lane == 0) S_mcount[mpair] = (unsigned)nlive;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) st = atomicCAS(&S_mstate[mpair], 0u, 1u);
+            st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
+            if (st == 0u) {          // handed over: this wave is done
+              active = false; p.flags = 0; p.helix = 0; ev = false; ev_x = false;
+            }
+            mrole = 0; mpoll_mask = ~0u;     // (st == 2: the receiver had already left -- carry on alone)
+          }
+        }
       }
       if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
         if (exhausted) break;
@@ -1325,12 +1506,45 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // (ev and ev_x are false for a particle that has not moved yet; F_NEARFEB is one of the flags)
     const bool unusual = p.flags != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass;
     PROF_LANES(13, active && (ev || ev_x || unusual));
+#ifdef MCS_PROF_TAIL
+    const bool rare_any__ = exhausted && __builtin_amdgcn_ballot_w64(active && (ev || ev_x || unusual)) != 0ull;
+    unsigned long long tt0__ = 0;
+    if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
+#endif
     if (MCS_UNLIKELY(active && (ev || ev_x || unusual))) {
       PROF_ADD(12, 1);
       const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
       int end = -1;
-      bool full = unusual || ev || h.etf || h.custom_epsB;
-      if (!full) full = !plain_crossing(a, h, p, ev_pending);
+      // What is due, from the state the move left (the expressions of move_and_detect).  A lane with nothing but
+      // a plain zone crossing, a time cut, a fine/coarse switch or the cos_max refresh that follows one takes the
+      // light path: those leave every other derived quantity as it is (see slow_post / slow_pre, whose remaining
+      // statements are no-ops then); anything else -- flags, an upward threshold, the age limit, odd
+      // configurations -- goes through the full Code Blocks.
+      const bool up_due = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
+      const bool t_due = ev && p.downstream && p.acctime >= p.t_ev;
+      const bool xn_due = ev && ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));
+      const bool age_out = h.age_max > 0 && p.acctime > h.age_max;
+      bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || h.etf || h.custom_epsB ||
+                  (ev && (h.odd_cfg || up_due || age_out));
+      if (!full && ev_x) full = !plain_crossing(a, h, p, ev_pending);
+      if (!full) {
+        if (p.flags & F_CM) {
+          refresh_scatter(a, p, h.aa, h.aa * MP_ * CC_, h.eta);
+          p.flags = 0;
+        }
+        if (t_due) {      // slow_post's time cut (cuts.jl:149-162)
+          if (h.do_tcuts && !(p.tcut > h.n_tcuts) && p.acctime >= tcut_next_of(a, h, p.tcut)) {
+            tcut_track(a, p.tcut, p.weight, p.ptot_pf);
+            p.tcut += 1;
+          }
+          refresh_time(a, h, p);
+        }
+        if (xn_due) {     // slow_pre's fine / coarse step (particle_loop.jl:382-385)
+          p.xn_per = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
+          p.flags |= F_CM;
+          refresh_move(a, h, p);
+        }
+      }
       PROF_LANES(16, full);
 #ifdef MCS_PROF
       if (exhausted) { xr__ += 1; xf__ += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(full)); }
@@ -1346,17 +1560,27 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         PROF_LANES(29, !moved);
       }
 #endif
+#ifdef MCS_PROF_TAIL
+#define TT_MARK(slot) do { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); if (exhausted && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], tn__ - tm__); tm__ = __builtin_amdgcn_s_memtime(); } while (0)
+      unsigned long long tm__ = __builtin_amdgcn_s_memtime();
+#else
+#define TT_MARK(slot) do { } while (0)
+#endif
       if (full) {
+        PROF_ADD(21, 1);
+        TT_MARK(20);
         bool pend = post_pending;
         for (;;) {
-          if (pend) { end = slow_post(a, s, h, rng, p, phi_prev); if (end >= 0) break; }
+          if (pend) { TTG_START(); end = slow_post(a, s, h, rng, p, phi_prev); if (end >= 0) break; }
           if (!(p.flags & F_B1)) break;
           pend = block1_step(a, h, p, phi_prev, end);
           if (end >= 0) break;
           pend = pend || (p.flags & F_NEARFEB) != 0;
           t_clock = p.t_step;
         }
+        TT_MARK(17);
         if (end < 0) end = slow_pre(a, s, h, kc, rng, p, t_clock);
+        TT_MARK(18);
       }
       if (end >= 0) {
         PROF_ADD(10, 1);
@@ -1382,8 +1606,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         }
         active = false;
         p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
+        TT_MARK(19);
       }
     }
+#ifdef MCS_PROF_TAIL
+    if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
+#endif
     // ---- the common pass, for every lane (idle lanes compute on stale state; nothing is stored)
     p.helix += 1;
     if (!h.dont_scatter) scattering(rng, p, kc);

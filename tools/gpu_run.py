@@ -31,8 +31,9 @@ for ip in range(1, NPC + 1):
     i64 = np.zeros(hb.layout.n_i64, dtype=np.int64)
     hb.lib.mcs_read_tallies(hb.h, None, i64.ctypes.data_as(ct.POINTER(ct.c_int64)))
     st = int(i64[ng + IC["STEPS_HELIX"]] + i64[ng + IC["STEPS_RETRO"]]); d = st - prev; prev = st
+    retro = int(i64[ng + IC["STEPS_RETRO"]])
     ms = hb.last_kernel_ms(); tot_ms += ms; tot_steps += d
-    print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3+1e-12):.3e} steps/s", flush=True)
+    print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3+1e-12):.3e} steps/s retro_cum={retro}", flush=True)
     if ns == 0: break
     hb.new_pcut(max(N // ns, 1))
 print(f"TOTAL steps={tot_steps} kernel_ms={tot_ms:.1f} rate={tot_steps/(tot_ms*1e-3):.3e} steps/s")

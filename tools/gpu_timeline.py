@@ -43,17 +43,17 @@ for ip in range(1, max(PC) + 1):
             cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
             import collections
             byc = collections.defaultdict(list)
-            for g in range(nw): byc[int(cuid[g])].append((int(simd[g]), int(slot[g]), g // 4, g % 4))
+            for g in range(nw): byc[int(cuid[g])].append((int(simd[g]), int(slot[g]), g // 4, g % 4, int(en[g]), int(w[g, 4])))
             print(f"   distinct CUs used: {len(byc)}")
             for c in list(sorted(byc))[:6]:
-                print(f"      cu {c}: (simd, slot, block, wave) = {sorted(byc[c])}")
+                print(f"      cu {c}: (simd, slot, block, wave, end us, passes after exhaustion) = {sorted(byc[c])}")
             same = sum(1 for g in range(0, nw, 4) if len(set(simd[g:g+4])) == 4 and all(simd[g + i] == (simd[g] + i) % 4 for i in range(4)))
             print(f"   blocks whose waves 0..3 sit on SIMDs s, s+1, s+2, s+3: {same} of {nw//4}; wave w on SIMD w: {sum(1 for g in range(nw) if simd[g] == g % 4)} of {nw}")
             sl = collections.Counter((int(slot[g]) for g in range(nw))); print(f"   wave-slot histogram: {dict(sl)}")
             blkslot = sum(1 for g in range(0, nw, 4) if len(set(slot[g:g+4])) == 1); print(f"   blocks whose 4 waves have the same slot id: {blkslot} of {nw//4}")
             partner = collections.Counter()
             for c, lst in byc.items():
-                blocks = sorted(set(b for _, _, b, _ in lst))
+                blocks = sorted(set(t[2] for t in lst))
                 if len(blocks) == 2: partner[blocks[1] - blocks[0]] += 1
                 else: partner[('n', len(blocks))] += 1
             print(f"   block-id distance of the two blocks sharing a CU: {dict(partner)}")
