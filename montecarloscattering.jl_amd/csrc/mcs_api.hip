@@ -75,6 +75,8 @@ struct mcs_ctx {
   long long f_cap = 0;
   // scan scratch
   unsigned int* d_bcounts = nullptr; unsigned long long* d_boffs = nullptr; long long* d_src = nullptr; long long scan_cap = 0;
+  double* d_park = nullptr;                    // park buffer of the transport kernel (KArgs::park)
+  bool park = true;                           // MCS_PARK=0: no parking (A/B measurements)
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
   // staging for init_pop
   double* d_stage = nullptr; long long stage_cap = 0;
@@ -220,6 +222,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   mcs_ctx* c = new mcs_ctx();
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
   c->device = device;
@@ -232,6 +235,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
+  HIPCHK(hipMalloc((void**)&c->d_park, (size_t)MCS_PARK_WAVES * MCS_PARK_SLOTS * MCS_PARK_WORDS * sizeof(double)));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
   HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
@@ -252,7 +256,7 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args,
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park,
                   c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
@@ -510,6 +514,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
                                      (long long)(i_pcut - 1) * c->P.n_pts_max);
   a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
   a.tail_merge = c->tail_merge ? 1 : 0;
+  a.park = c->park ? c->d_park : nullptr;
   a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
 
   const int threads = c->threads;
@@ -517,7 +522,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   if (blocks <= 0) {
     // persistent lanes: fill the chip, never launch more lanes than particles
     const long long want = (n + threads - 1) / threads;
-    const long long full = (long long)c->n_cu * 4;     // 4 x 256-thread blocks per CU
+    const long long full = (long long)c->n_cu * 2;     // two 256-thread blocks are resident per CU (76 KB of LDS each)
     blocks = (int)(want < full ? want : full);
     if (blocks < 1) blocks = 1;
   }

@@ -46,8 +46,14 @@ struct KArgs {
   unsigned long long* n_saved;
   int32_t *f_reason, *f_helix, *f_retro;
   double *f_ptot, *f_x;
+  double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
 };
+
+// particles waiting for their full Code Blocks, per wave (see the park logic of the transport kernel)
+#define MCS_PARK_SLOTS 16
+#define MCS_PARK_WORDS 36
+#define MCS_PARK_WAVES 4096   // launches with more waves than this do not park
 
 // zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old

@@ -48,6 +48,9 @@
 #ifndef MCS_REFILL_MIN
 #define MCS_REFILL_MIN 8        // idle lanes a wave collects before it claims new particles (measured: 1 -> 630 ms, 2 -> 617, 4 -> 615, 8 -> 610, 16 -> 611)
 #endif
+#ifndef MCS_PARK_HELIX_MAX
+#define MCS_PARK_HELIX_MAX 512  // only particles younger than this many passes park
+#endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
 // calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
 #ifdef MCS_INLINE_COLD
@@ -199,6 +202,7 @@ struct Lds {                                // kept as an (empty) handle so call
 #define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
 #define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
 #define F_CM      0x200   // only cos_max is stale (fine/coarse switch in the last pass): refresh_scatter alone
+#define F_NOPARK  0x400   // just resumed from the park buffer: run the full Code Blocks now
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double dphi;                   // 2pi / xn_per (particle_loop.jl:529)
@@ -254,7 +258,11 @@ __device__ unsigned long long g_wave[8192][8];   // per wave: start, counter exh
 __shared__ unsigned long long S_prof[MCS_NPROF];
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #ifdef MCS_PROF_TAIL   // count only the passes after the work counter is exhausted
+#ifdef MCS_PROF_ALLPHASES   // the same timers over the whole launch
+#define PROF_GATE true
+#else
 #define PROF_GATE exhausted
+#endif
 __shared__ unsigned int S_ttgate[4];            // 1 once this wave found the work counter exhausted
 __shared__ unsigned long long S_tttm[4];        // time of the last mark of this wave
 #define TTG_START() do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) S_tttm[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1086,7 +1094,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
       f |= F_RS | F_RM;
     }
   }
-  f &= ~(F_ZONE | F_CROSSED | F_CHECK);
+  f &= ~(F_ZONE | F_CROSSED | F_CHECK | F_NOPARK);
   p.flags = f;
   // exit tests of Code Block 3 (particle_loop.jl:251-300), after the transforms
   const int ig = p.ig3;
@@ -1240,34 +1248,38 @@ __shared__ unsigned int S_mlive[4];     // live lanes an exhausted receiver last
 __shared__ unsigned int S_mstate[2];    // per SIMD pair: 0 open, 1 donated, 2 closed
 __shared__ unsigned int S_mcount[2];    // particles in the mailbox
 
-__device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x,
-                                         bool moved, double phi_prev) {
-  double* mb = &S_evf[box][0][0] + r;
+template <int STRIDE>
+__device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x, bool moved,
+                                            double phi_prev) {
   const double v[30] = {p.weight, p.ptot_pf, p.pb_pf, p.p_perp, p.gam_pf, p.x, p.x_old, p.phi, p.prp, p.acctime, p.xn_per, p.dphi,
                         p.gyro_denom, p.gyro_rad, p.gyro_rad_tot, p.gyro_period, p.t_step, p.rp_val, p.cm_val, p.rg_val, p.x_dt,
                         p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, rng.spare, phi_prev};
 #pragma unroll
-  for (int j = 0; j < 30; ++j) mb[j * MCS_MB_SLOTS] = v[j];
-  mb[30 * MCS_MB_SLOTS] = __longlong_as_double(k);
+  for (int j = 0; j < 30; ++j) mb[j * STRIDE] = v[j];
+  mb[30 * STRIDE] = __longlong_as_double(k);
   const int gridpack = p.i_grid | (p.i_grid_old << 8) | (p.ig3 << 16) | (p.tcut << 24);
   const int bits = p.ovr_inc | ((int)p.downstream << 1) | ((int)p.inj << 2) | ((int)ev << 3) | ((int)ev_x << 4) | ((int)moved << 5);
-  mb[31 * MCS_MB_SLOTS] = __hiloint2double(p.flags, (int)p.n_ovr);
-  mb[32 * MCS_MB_SLOTS] = __hiloint2double(gridpack, p.helix);
-  mb[33 * MCS_MB_SLOTS] = __hiloint2double(p.n_retro, bits);
-  mb[34 * MCS_MB_SLOTS] = __hiloint2double((int)rng.k0, (int)rng.k1);
-  mb[35 * MCS_MB_SLOTS] = __hiloint2double((int)rng.n, 0);
+  mb[31 * STRIDE] = __hiloint2double(p.flags, (int)p.n_ovr);
+  mb[32 * STRIDE] = __hiloint2double(gridpack, p.helix);
+  mb[33 * STRIDE] = __hiloint2double(p.n_retro, bits);
+  mb[34 * STRIDE] = __hiloint2double((int)rng.k0, (int)rng.k1);
+  mb[35 * STRIDE] = __hiloint2double((int)rng.n, 0);
 }
-__device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
-                                        double& phi_prev) {
-  const double* mb = &S_evf[box][0][0] + r;
+template <int STRIDE, bool COHERENT>
+__device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
+                                           double& phi_prev) {
+  // COHERENT: the wave reads back what it stored to global memory earlier -- agent-scope loads, past the L1
+  auto LD = [&](int j) -> double {
+    if (COHERENT) return __hip_atomic_load(mb + j * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mb[j * STRIDE];
+  };
   double* const d[30] = {&p.weight, &p.ptot_pf, &p.pb_pf, &p.p_perp, &p.gam_pf, &p.x, &p.x_old, &p.phi, &p.prp, &p.acctime, &p.xn_per,
                          &p.dphi, &p.gyro_denom, &p.gyro_rad, &p.gyro_rad_tot, &p.gyro_period, &p.t_step, &p.rp_val, &p.cm_val,
                          &p.rg_val, &p.x_dt, &p.t_ev, &p.z_gsf, &p.z_bcos, &p.z_ux, &p.z_gef, &p.z_lo, &p.z_hi, &rng.spare, &phi_prev};
 #pragma unroll
-  for (int j = 0; j < 30; ++j) *d[j] = mb[j * MCS_MB_SLOTS];
-  k = __double_as_longlong(mb[30 * MCS_MB_SLOTS]);
-  const double w1 = mb[31 * MCS_MB_SLOTS], w2 = mb[32 * MCS_MB_SLOTS], w3 = mb[33 * MCS_MB_SLOTS], w4 = mb[34 * MCS_MB_SLOTS],
-               w5 = mb[35 * MCS_MB_SLOTS];
+  for (int j = 0; j < 30; ++j) *d[j] = LD(j);
+  k = __double_as_longlong(LD(30));
+  const double w1 = LD(31), w2 = LD(32), w3 = LD(33), w4 = LD(34), w5 = LD(35);
   p.flags = __double2hiint(w1); p.n_ovr = (unsigned)__double2loint(w1);
   const int gridpack = __double2hiint(w2);
   p.helix = __double2loint(w2);
@@ -1279,6 +1291,21 @@ __device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rn
   rng.k0 = (uint32_t)__double2hiint(w4); rng.k1 = (uint32_t)__double2loint(w4);
   rng.n = (uint32_t)__double2hiint(w5);
   p.npush = 0;
+}
+
+__device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x,
+                                         bool moved, double phi_prev) {
+  state_store<MCS_MB_SLOTS>(&S_evf[box][0][0] + r, p, rng, k, ev, ev_x, moved, phi_prev);
+}
+__device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
+                                        double& phi_prev) {
+  state_load<MCS_MB_SLOTS, false>(&S_evf[box][0][0] + r, p, rng, k, ev, ev_x, moved, phi_prev);
+}
+static_assert(MCS_PARK_WORDS == MCS_MB_WORDS, "one state layout");
+
+// number of set bits of `m` below this lane (v_mbcnt: no per-lane mask register)
+__device__ __forceinline__ unsigned below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 // PLAIN = the common configuration, decided by the host: scattering on, parallel field in every zone,
@@ -1308,7 +1335,11 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   if (threadIdx.x < 3) S_steps[threadIdx.x] = 0ull;
   if (threadIdx.x < 4) { S_evcur[threadIdx.x] = 0u; S_mlive[threadIdx.x] = 64u; }
 #ifdef MCS_PROF_TAIL
+#ifdef MCS_PROF_ALLPHASES
+  if (threadIdx.x < 4) S_ttgate[threadIdx.x] = 1u;
+#else
   if (threadIdx.x < 4) S_ttgate[threadIdx.x] = 0u;
+#endif
 #endif
   if (threadIdx.x < 2) { S_mstate[threadIdx.x] = 0u; S_mcount[threadIdx.x] = 0u; }
   if ((threadIdx.x & 63u) == 0u) S_msimd[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
@@ -1376,25 +1407,42 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const unsigned wv = threadIdx.x >> 6;
   // tail consolidation (see mb_store): role of this wave, decided once
   int mrole = 0;                    // 0 none / done, 1 donor, 2 receiver
-  unsigned mpartner = 0, mpair = 0;
   unsigned mtick = 0, mpoll_mask = ~0u;     // the poll happens when (mtick & mpoll_mask) == 0: never before exhaustion
   if (blockDim.x == 256u && a->tail_merge) {
     const unsigned s0 = S_msimd[0], s1 = S_msimd[1], s2 = S_msimd[2], s3 = S_msimd[3];
     const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 15u;
-    const unsigned mine = S_msimd[wv], want = mine ^ 1u;
-    const unsigned partner = s0 == want ? 0u : (s1 == want ? 1u : (s2 == want ? 2u : 3u));
     const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-    if (__builtin_amdgcn_readfirstlane(distinct ? 1 : 0)) {
-      mpartner = (unsigned)__builtin_amdgcn_readfirstlane((int)partner);
-      mpair = (unsigned)__builtin_amdgcn_readfirstlane((int)(mine >> 1));
-      mrole = __builtin_amdgcn_readfirstlane((int)(((mine ^ slot) & 1u) == 0u ? 2 : 1));
-    }
+    if (__builtin_amdgcn_readfirstlane(distinct ? 1 : 0))
+      mrole = __builtin_amdgcn_readfirstlane((int)(((S_msimd[wv] ^ slot) & 1u) == 0u ? 2 : 1));
   }
+  // the pair (SIMDs 2q, 2q+1) and the partner's wave index, looked up at the (rare) uses
+  auto pair_of = [&](unsigned& partner) -> unsigned {
+    const unsigned mine = S_msimd[wv], want = mine ^ 1u;
+    const unsigned pw = S_msimd[0] == want ? 0u : (S_msimd[1] == want ? 1u : (S_msimd[2] == want ? 2u : 3u));
+    partner = (unsigned)__builtin_amdgcn_readfirstlane((int)pw);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(mine >> 1));
+  };
 #ifdef MCS_PROF
   const unsigned gw__ = (blockIdx.x * 4u + wv) & 8191u;
   if (lane == 0) { g_wave[gw__][0] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][1] = 0; }
   unsigned long long xp__ = 0, xr__ = 0, xl__ = 0, xf__ = 0;   // after exhaustion: passes, rare entries, live-lane sum, full-path lanes
 #endif
+  // Parking: a lane whose particle needs the full Code Blocks (an upward threshold, the shock, a zone with another
+  // flow speed, ...) used to run them on the spot -- thousands of cycles for one or two lanes while the wave waits.
+  // Instead it writes the particle's state to this wave's park buffer (global memory) and goes idle; the next
+  // refill (MCS_REFILL_MIN idle lanes) takes the parked particles back first, so that they run the Code Blocks
+  // together, in one pass.  Only young particles park (a long history is what the launch waits for at the end),
+  // and nothing parks once the work counter is exhausted.  The state and the RNG stream travel with the particle.
+  // (readfirstlane: the compiler must see these as wave-uniform, or every scalar branch that depends on them
+  // turns into an exec-mask region)
+  const bool parking = __builtin_amdgcn_readfirstlane((int)(a->park != nullptr && blockDim.x == 256u && blockIdx.x * 4u + wv < (unsigned)MCS_PARK_WAVES)) != 0;
+  auto park_ptr = [&]() -> double* {      // recomputed at the (rare) uses: no registers held across the loop
+    return a->park + (size_t)(blockIdx.x * 4u + wv) * (MCS_PARK_SLOTS * MCS_PARK_WORDS);
+  };
+  unsigned n_parked = 0;            // wave-uniform
+  // idle lanes at which the wave has housekeeping to do: MCS_REFILL_MIN while there is unclaimed work; afterwards 1
+  // while parked particles wait for a lane, else 64 (nothing left: the wave ends)
+  unsigned refill_at = MCS_REFILL_MIN;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.npush = 0;
   for (;;) {
@@ -1407,11 +1455,26 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // passes (late pcuts) a lane idles every 3-4 passes and refilling each at once cost ~25 % of the time.
     const int n_idle = 64 - __popcll(act_mask);
     ++mtick;
-    if (MCS_UNLIKELY(ev_pending >= 64u || (n_idle >= MCS_REFILL_MIN && !exhausted) || act_mask == 0ull || (mtick & mpoll_mask) == 0u)) {
+    // (bitwise | on purpose: one scalar branch, not a chain of short-circuit branches)
+    if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
       if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
+      // parked particles first: they run their Code Blocks together in the coming pass
+      if (n_parked > 0u && n_idle > 0 && (exhausted || n_idle >= MCS_REFILL_MIN)) {
+        const unsigned take = n_parked < (unsigned)n_idle ? n_parked : (unsigned)n_idle;
+        const unsigned r = below(~act_mask);
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's stores to the park buffer have landed
+        if (!active && r < take) {
+          state_load<MCS_PARK_SLOTS, true>(park_ptr() + (n_parked - take + r), p, rng, k, ev, ev_x, moved, phi_prev);
+          p.flags |= F_NOPARK;
+          active = true;
+        }
+        n_parked -= take;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        PROF_ADD(36, 1); PROF_ADD(37, take);
+      }
       // refill idle lanes (wave-aggregated claim)
-      const unsigned long long idle = ~act_mask;
-      if (n_idle >= MCS_REFILL_MIN && !exhausted) {
+      const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(active);
+      if (n_idle >= MCS_REFILL_MIN && !exhausted && idle != 0ull) {
         const int nidle = __popcll(idle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned long long base = 0;
@@ -1427,7 +1490,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           if (lane == 0 && g_wave[gw__][1] == 0) { g_wave[gw__][1] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][3] = (unsigned long long)__popcll(act_mask); }
 #endif
         } else if (!active) {
-          const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+          const int rank = (int)below(idle);
           const unsigned long long idx = base + (unsigned long long)rank;
           if (idx < n) {
             k = (long long)idx;
@@ -1441,19 +1504,20 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         PROF_ADD(5, 1); PROF_ADD(6, nidle);
       }
       // ---- tail consolidation (see mb_store); `exhausted` holds whenever mpoll_mask is 15
-      const unsigned long long lt_mask = (1ull << lane) - 1ull;
-      auto take_donation = [&]() {
+      auto take_donation = [&](unsigned mpair, unsigned mpartner) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const unsigned cntm = (unsigned)__builtin_amdgcn_readfirstlane((int)S_mcount[mpair]);
         const unsigned long long idle_now = ~__builtin_amdgcn_ballot_w64(active);
-        const unsigned r = (unsigned)__popcll(idle_now & lt_mask);
+        const unsigned r = below(idle_now);
         if (!active && r < cntm) {
           mb_load(mpartner, r, p, rng, k, ev, ev_x, moved, phi_prev);
           active = true;
         }
         mrole = 0; mpoll_mask = ~0u;
       };
-      if (mrole != 0 && exhausted) {
+      if (mrole != 0 && exhausted && n_parked == 0u) {
+        unsigned mpartner;
+        const unsigned mpair = pair_of(mpartner);
         const int nlive = __popcll(__builtin_amdgcn_ballot_w64(active));
         if (mrole == 2) {
           // receiver: publish the room (live lanes only decrease from now on), look for a donation; when it
@@ -1465,7 +1529,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           }
           st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
           if (st == 1u) {
-            take_donation();
+            take_donation(mpair, mpartner);
             if (lane == 0) S_mstate[mpair] = 2u;
           } else if (st == 2u || nlive == 0) { mrole = 0; mpoll_mask = ~0u; }
         } else {
@@ -1476,7 +1540,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           } else if (nlive <= MCS_MB_SLOTS && nlive <= room) {
             // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
             drain_events(a, s, wv, lane, true); ev_pending = 0u;
-            if (active) mb_store(wv, (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active) & lt_mask), p, rng, k, ev, ev_x, moved, phi_prev);
+            if (active) mb_store(wv, below(__builtin_amdgcn_ballot_w64(active)), p, rng, k, ev, ev_x, moved, phi_prev);
             unsigned st = 2u;
             if (lane == 0) S_mcount[mpair] = (unsigned)nlive;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1489,8 +1553,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           }
         }
       }
+      if (exhausted) refill_at = n_parked > 0u ? 1u : 64u;
       if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
-        if (exhausted) break;
+        if (exhausted && n_parked == 0u) break;
         continue;
       }
     }
@@ -1507,12 +1572,19 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     const bool unusual = p.flags != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass;
     PROF_LANES(13, active && (ev || ev_x || unusual));
 #ifdef MCS_PROF_TAIL
-    const bool rare_any__ = exhausted && __builtin_amdgcn_ballot_w64(active && (ev || ev_x || unusual)) != 0ull;
+    const bool rare_any__ = PROF_GATE && __builtin_amdgcn_ballot_w64(active && (ev || ev_x || unusual)) != 0ull;
     unsigned long long tt0__ = 0;
     if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
 #endif
+    bool parked_now = false;
     if (MCS_UNLIKELY(active && (ev || ev_x || unusual))) {
       PROF_ADD(12, 1);
+#ifdef MCS_PROF_TAIL
+#define TT_MARK(slot) do { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); if (PROF_GATE && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], tn__ - tm__); tm__ = __builtin_amdgcn_s_memtime(); } while (0)
+      unsigned long long tm__ = __builtin_amdgcn_s_memtime();
+#else
+#define TT_MARK(slot) do { } while (0)
+#endif
       const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
       int end = -1;
       // What is due, from the state the move left (the expressions of move_and_detect).  A lane with nothing but
@@ -1526,8 +1598,22 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       const bool age_out = h.age_max > 0 && p.acctime > h.age_max;
       bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || h.etf || h.custom_epsB ||
                   (ev && (h.odd_cfg || up_due || age_out));
+      TT_MARK(32);
       if (!full && ev_x) full = !plain_crossing(a, h, p, ev_pending);
-      if (!full) {
+      TT_MARK(33);
+      if (parking && !exhausted) {
+        if (full && moved && (p.flags & F_NOPARK) == 0 && p.helix < MCS_PARK_HELIX_MAX) {
+          const unsigned slot = n_parked + below(__builtin_amdgcn_ballot_w64(true));
+          if (slot < (unsigned)MCS_PARK_SLOTS) {
+            state_store<MCS_PARK_SLOTS>(park_ptr() + slot, p, rng, k, ev, ev_x, moved, phi_prev);
+            parked_now = true;
+            full = false;
+            active = false; ev = false; ev_x = false;
+            p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
+          }
+        }
+      }
+      if (!full && !parked_now) {
         if (p.flags & F_CM) {
           refresh_scatter(a, p, h.aa, h.aa * MP_ * CC_, h.eta);
           p.flags = 0;
@@ -1545,6 +1631,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           refresh_move(a, h, p);
         }
       }
+      TT_MARK(34);
       PROF_LANES(16, full);
 #ifdef MCS_PROF
       if (exhausted) { xr__ += 1; xf__ += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(full)); }
@@ -1559,12 +1646,6 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         PROF_LANES(28, (p.flags & F_SAVE) != 0);
         PROF_LANES(29, !moved);
       }
-#endif
-#ifdef MCS_PROF_TAIL
-#define TT_MARK(slot) do { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); if (exhausted && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], tn__ - tm__); tm__ = __builtin_amdgcn_s_memtime(); } while (0)
-      unsigned long long tm__ = __builtin_amdgcn_s_memtime();
-#else
-#define TT_MARK(slot) do { } while (0)
 #endif
       if (full) {
         PROF_ADD(21, 1);
@@ -1612,6 +1693,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF_TAIL
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
+    if (parking && !exhausted) n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));
     // ---- the common pass, for every lane (idle lanes compute on stale state; nothing is stored)
     p.helix += 1;
     if (!h.dont_scatter) scattering(rng, p, kc);

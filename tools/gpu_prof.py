@@ -41,6 +41,7 @@ for ip in range(1, NPC + 1):
         print(f"   lanes per entry with: xn switch due {P[22]/e:.2f}, x>=x_up {P[23]/e:.2f}, time event {P[24]/e:.2f}, refresh flags {P[25]/e:.2f}, crossing not plain {P[26]/e:.2f}, near FEB {P[27]/e:.2f}, to be saved {P[28]/e:.2f}, new particle {P[29]/e:.2f}")
         if P[31] > 0: print(f"   (MCS_PROF_TAIL) rare region after exhaustion: {P[31]:.3e} timed entries, {P[30]/P[31]:.0f} s_memtime ticks each (100 MHz x ? -- see tools/ubench)")
         if P[21] > 0: print(f"   (MCS_PROF_TAIL) per full-path group ({P[21]:.3e}): before {P[20]/P[21]:.0f}, slow_post+block1 {P[17]/P[21]:.0f}, slow_pre {P[18]/P[21]:.0f}, particle end {P[19]/max(P[10],1):.0f} per ended group ({P[10]:.3e})")
+        if P[32] > 0: print(f"   (MCS_PROF_TAIL) per entry ({P[12]:.3e}): classification {P[32]/P[12]:.0f}, plain_crossing {P[33]/P[12]:.0f}, light handlers {P[34]/P[12]:.0f}")
         if P[48:54].sum() > 0:
             names = ["time cut", "reflect/shock", "zone search + record", "downstream test", "prob_return (+retro walk)", "flags + refresh"]
             print("   (MCS_PROF_TAIL) slow_post sections, ticks per execution (executions): " + "; ".join(f"{nm} {P[40+i]/max(P[48+i],1):.0f} ({P[48+i]:.2e})" for i, nm in enumerate(names)) + f"; retro steps {P[39]:.3e}")
