@@ -49,7 +49,7 @@
 #define MCS_REFILL_MIN 8        // idle lanes a wave collects before it claims new particles (measured: 1 -> 630 ms, 2 -> 617, 4 -> 615, 8 -> 610, 16 -> 611)
 #endif
 #ifndef MCS_PARK_HELIX_MAX
-#define MCS_PARK_HELIX_MAX 512  // only particles younger than this many passes park
+#define MCS_PARK_HELIX_MAX 2048 // only particles younger than this many passes park
 #endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
 // calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
@@ -1601,6 +1601,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       TT_MARK(32);
       if (!full && ev_x) full = !plain_crossing(a, h, p, ev_pending);
       TT_MARK(33);
+      // most entries are plain crossings and nothing else: one scalar branch skips what follows (a dozen
+      // conditional regions at ~40 cycles each even when no lane takes them)
+      if (__builtin_amdgcn_ballot_w64(full || (p.flags & F_CM) != 0 || t_due || xn_due) != 0ull) {
       if (parking && !exhausted) {
         if (full && moved && (p.flags & F_NOPARK) == 0 && p.helix < MCS_PARK_HELIX_MAX) {
           const unsigned slot = n_parked + below(__builtin_amdgcn_ballot_w64(true));
@@ -1688,6 +1691,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         active = false;
         p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
         TT_MARK(19);
+      }
       }
     }
 #ifdef MCS_PROF_TAIL
