@@ -231,6 +231,37 @@ def test_specialised_and_general_kernel_agree(monkeypatch):
     assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
 
 
+def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
+    """K1 moves particles between lanes: a lane that needs the full Code Blocks parks its particle until the next
+    refill (MCS_PARK), and sparse waves of a block merge after the work counter is exhausted (MCS_TAIL_MERGE).
+    The state and the RNG stream travel with the particle: with both switched off the particles are bit-identical.
+    Few blocks, so that every lane is refilled many times and both mechanisms have work."""
+    N = 6000
+    prob = make_problem(N)
+    out = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MCS_PARK", on)
+        monkeypatch.setenv("MCS_TAIL_MERGE", on)
+        hb = hip_backend(prob)
+        hb.set_launch(4, 256)
+        start_species(hb, prob)
+        fin = []
+        for ip in range(1, 12):
+            ns = hb.run_pcut(ip, 0)
+            fin.append((hb.finals(), hb.get_saved()))
+            hb.new_pcut(max(N // ns, 1))
+        out.append((fin, hb.read_tallies()))
+        hb.destroy()
+    (fa, (Ta, Ia)), (fb, (Tb, Ib)) = out
+    for (xa, (sa, la)), (xb, (sb, lb)) in zip(fa, fb):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), k
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, "saved arrays, with and without parking / tail consolidation")
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
+
+
 def test_results_do_not_depend_on_launch_geometry():
     """Which lane runs which particle is irrelevant: few blocks (lanes are refilled many
     times) and the automatic geometry give bit-identical particles."""
