@@ -1569,7 +1569,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
     // ---- the one rare region (see the comment above move_and_detect)
     // (ev and ev_x are false for a particle that has not moved yet; F_NEARFEB is one of the flags)
-    const bool unusual = p.flags != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass;
+    // (| and &: one condition, one conditional region -- && / || compile to nested exec-mask regions)
+    const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
     PROF_LANES(13, active && (ev || ev_x || unusual));
 #ifdef MCS_PROF_TAIL
     const bool rare_any__ = PROF_GATE && __builtin_amdgcn_ballot_w64(active && (ev || ev_x || unusual)) != 0ull;
@@ -1577,7 +1578,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
 #endif
     bool parked_now = false;
-    if (MCS_UNLIKELY(active && (ev || ev_x || unusual))) {
+    if (MCS_UNLIKELY(active & (ev | ev_x | unusual))) {
       PROF_ADD(12, 1);
 #ifdef MCS_PROF_TAIL
 #define TT_MARK(slot) do { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); if (PROF_GATE && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], tn__ - tm__); tm__ = __builtin_amdgcn_s_memtime(); } while (0)
