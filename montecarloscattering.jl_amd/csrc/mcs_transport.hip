@@ -265,6 +265,7 @@ __shared__ unsigned long long S_prof[MCS_NPROF];
 #endif
 __shared__ unsigned int S_ttgate[4];            // 1 once this wave found the work counter exhausted
 __shared__ unsigned long long S_tttm[4];        // time of the last mark of this wave
+#define TTG_COUNT(slot) do { if (S_ttgate[threadIdx.x >> 6]) atomicAdd(&S_prof[slot], 1ull); } while (0)
 #define TTG_START() do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) S_tttm[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TTG_MARK(slot) do { if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); \
     if (S_ttgate[threadIdx.x >> 6]) { atomicAdd(&S_prof[slot], tn__ - S_tttm[threadIdx.x >> 6]); atomicAdd(&S_prof[(slot) + 8], 1ull); } S_tttm[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -279,6 +280,7 @@ __shared__ unsigned long long S_tttm[4];        // time of the last mark of this
 #define PROF_LANES(slot, pred) do { } while (0)
 #endif
 #ifndef MCS_PROF_TAIL
+#define TTG_COUNT(slot) do { } while (0)
 #define TTG_START() do { } while (0)
 #define TTG_MARK(slot) do { } while (0)
 #endif
@@ -738,14 +740,17 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
     const double grt = p.ptot_pf * CC_ * gyro_tmp / (MCS_QCGS * P.bmag2);
     const double L_diff = eta / 3 * grt * p.ptot_pf / (aa * MP_ * p.gam_pf * u2);
     p.prp = p.x + 3 * L_diff;
+    TTG_COUNT(56);
   } else if (p.x_old < p.prp && p.x >= p.prp) {
     const double vt = p.ptot_pf / (p.gam_pf * aa * MP_);
     const double q = (vt - u2) / (vt + u2);
     const double prob_ret = q * q;
     if (vt < u2 || rng.rand() > prob_ret) {
       i_return = 0;
+      TTG_COUNT(57);
     } else {
       i_return = 1;
+      TTG_COUNT(58);
       Retro r;
       r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
       r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = tcut_next_of(a, h, p.tcut); r.tcut = p.tcut;
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
       v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
     }
     const double L_diff = h.eta / 3 * v_fac;
-    if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; }
+    if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; TTG_COUNT(59); }
   }
   bool lose_pt = false;
   TTG_MARK(43);

@@ -46,6 +46,7 @@ for ip in range(1, NPC + 1):
             names = ["time cut", "reflect/shock", "zone search + record", "downstream test", "prob_return (+retro walk)", "flags + refresh"]
             print("   (MCS_PROF_TAIL) slow_post sections, ticks per execution (executions): " + "; ".join(f"{nm} {P[40+i]/max(P[48+i],1):.0f} ({P[48+i]:.2e})" for i, nm in enumerate(names)) + f"; retro steps {P[39]:.3e}")
         if P[36] > 0: print(f"   parked particles resumed: {P[37]:.3e} in {P[36]:.3e} refills ({P[37]/P[36]:.1f} each)")
+        if P[56:60].sum() > 0: print(f"   (MCS_PROF_TAIL) upward events after exhaustion: grid end crossed {P[56]:.3e}, PRP escape {P[57]:.3e}, PRP return (retro walk) {P[58]:.3e}, beyond x_dt {P[59]:.3e}")
         print(f"   drains/pass {P[3]/passes:.4f}  refills/pass {P[5]/passes:.4f} ({P[6]/max(P[5],1):.1f} lanes each)  particles ended/pass {P[10]/passes:.4f}", flush=True)
     if ns == 0: break
     hb.new_pcut(max(N // ns, 1))
