@@ -864,14 +864,14 @@ __device__ __forceinline__ int zone_search(double x, bool fwd, int i_grid, int n
 // of the previous common pass and one for a Code Block 1 move (a second PRP return cannot follow
 // directly: the retro walk leaves the particle AT the PRP, and a return needs x_old < prp).
 // `known_base` >= 0: the stack height is known (first push site of the pass: the register mirror), no LDS read.
-__device__ __forceinline__ void push_record(Pt& p, int ig3, int known_base = -1) {
+__device__ __forceinline__ void push_record(Pt& p, int ig3, int known_base = -1, uint32_t tag = 0u) {
   const unsigned long long m_ev = __builtin_amdgcn_ballot_w64(true);   // lanes that are here now
   const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
   const unsigned base = known_base >= 0 ? (unsigned)known_base : S_evcur[wv];
   const unsigned pos = base + (unsigned)__popcll(m_ev & ((1ull << ln) - 1ull));
   S_evf[wv][0][pos] = p.pb_pf; S_evf[wv][1][pos] = p.p_perp; S_evf[wv][2][pos] = p.ptot_pf; S_evf[wv][3][pos] = p.gam_pf;
   S_evf[wv][4][pos] = p.phi; S_evf[wv][5][pos] = p.weight; S_evf[wv][6][pos] = p.x; S_evf[wv][7][pos] = p.x_old;
-  S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24);
+  S_evu[wv][pos] = (uint32_t)p.i_grid | ((uint32_t)p.i_grid_old << 8) | ((uint32_t)ig3 << 16) | ((uint32_t)(p.inj ? 1u : 0u) << 24) | tag;
   if (ln == (unsigned)(__ffsll((long long)m_ev) - 1)) S_evcur[wv] = base + (unsigned)__popcll(m_ev);
   p.npush += 1;
 }
@@ -1224,9 +1224,14 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
     if (lane < take) {
       const unsigned e = base + lane;
       const uint32_t u = S_evu[wv][e];
-      flux_tally(a, s, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
-                 S_evf[wv][6][e], S_evf[wv][7][e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu),
-                 ((u >> 24) & 1u) != 0u);
+      if (u >> 28) {     // a finished particle (particle_finish!): reason in bits 25-27
+        particle_finish(a, s, (int)((u >> 25) & 7u), S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][3][e], S_evf[wv][4][e],
+                        S_evf[wv][5][e], (int)((u >> 16) & 0xffu));
+      } else {
+        flux_tally(a, s, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
+                   S_evf[wv][6][e], S_evf[wv][7][e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu),
+                   ((u >> 24) & 1u) != 0u);
+      }
     }
     cnt = base;
   }
@@ -1687,6 +1692,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           a->sv.acctime_sec[k] = p.acctime; a->sv.phi_rad[k] = p.phi;
           a->sv.meta[k] = mcs_pack_meta(p.i_grid, p.tcut, p.downstream, p.inj);
           cnt(a, MCS_IC_COUNT);
+        } else if (p.npush < 2) {
+          // particle_finish! (transform, two bin look-ups, up to five tallies) is deferred like the zone-crossing
+          // tallies: a record on the wave's stack, tallied 64 at a time (a lane pushes at most two records per pass)
+          push_record(p, p.ig3, -1, (1u << 28) | ((uint32_t)end << 25));
         } else {
           particle_finish(a, s, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
         }
