@@ -1603,10 +1603,13 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // light path: those leave every other derived quantity as it is (see slow_post / slow_pre, whose remaining
       // statements are no-ops then); anything else -- flags, an upward threshold, the age limit, odd
       // configurations -- goes through the full Code Blocks.
-      const bool up_due = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
-      const bool t_due = ev && p.downstream && p.acctime >= p.t_ev;
-      const bool xn_due = ev && ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));
-      const bool age_out = h.age_max > 0 && p.acctime > h.age_max;
+      bool up_due = false, t_due = false, xn_due = false, age_out = false;
+      if (__builtin_amdgcn_ballot_w64(ev) != 0ull) {      // most entries are zone crossings only
+        up_due = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
+        t_due = ev & p.downstream & (p.acctime >= p.t_ev);
+        xn_due = ev & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));
+        age_out = (h.age_max > 0) & (p.acctime > h.age_max);
+      }
       bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || h.etf || h.custom_epsB ||
                   (ev && (h.odd_cfg || up_due || age_out));
       TT_MARK(32);
