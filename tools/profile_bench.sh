@@ -8,6 +8,7 @@ CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
+timeout -k 10 500 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/busy -- $CMD > $OUT/busy.log 2>&1
 timeout -k 10 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $CMD > $OUT/sq.log 2>&1
 python3 - <<PY
 import csv, glob, collections
@@ -17,7 +18,7 @@ def P(*a):
 for p in glob.glob("$OUT/stats/*/*kernel_stats.csv"):
     P("== kernel stats (rocprofv3 --kernel-trace --stats) of: $CMD")
     P(open(p).read())
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "sq", "busy"):
     for p in glob.glob("$OUT/%s/*/*counter_collection.csv" % name):
         agg = collections.defaultdict(float); n = collections.defaultdict(set)
         for r in csv.DictReader(open(p)):
