@@ -126,37 +126,33 @@ __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
   return __builtin_ldexp(__builtin_fma((double)h, 4294967296.0, (double)l), -53);
 }
 
-// Per-particle stream: draw j -> words (2*(j&1), 2*(j&1)+1) of block j>>1.  The odd
-// draw of a block is kept in a register so that two consecutive draws cost one block.
+// Per-particle stream: draw j -> words (2*(j&1), 2*(j&1)+1) of block j>>1.  The draw index is even wherever
+// a call site starts (see Rng in oracle/mcs_oracle.cpp): the two draws of a scatter are one block, a single draw
+// takes the first half of a block and skips the second -- no parity logic, no spare register.
 // (Computing the next step's block one step ahead -- off the critical path -- was tried and
 // gained nothing: hipcc does not interleave it with the fp64 chain under this register pressure.)
 struct Rng {
   uint32_t k0, k1;
-  uint32_t n;        // draws so far (a history makes < 2^32 draws)
-  double spare;
+  uint32_t n;        // draw index (a history stays < 2^32)
   __device__ __forceinline__ void init(unsigned long long key) {
-    k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); n = 0; spare = 0.0;
+    k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); n = 0;
   }
+  // a single draw: index n, then skip n+1
   __device__ __forceinline__ double rand() {
-    const uint32_t j = n++;
-    if (j & 1u) return spare;
+    const uint32_t j = n;
+    n = j + 2u;
     uint32_t o0, o1, o2, o3;
     philox_block(j >> 1, 0u, 0u /*STREAM_PARTICLE*/, 0u, k0, k1, o0, o1, o2, o3);
-    spare = u64_to_unit(o2, o3);
     return u64_to_unit(o0, o1);
   }
-  // Two consecutive draws (the pair of src/scattering.jl:68,71) with ONE Philox block and no
-  // branch on the parity of the draw counter: the block holding draw n+1 is always needed.
+  // the two draws of a scatter (src/scattering.jl:68,71): indices n, n+1 = one Philox block
   __device__ __forceinline__ void pair(double& u1, double& u2) {
     const uint32_t j = n;
     n = j + 2u;
     uint32_t o0, o1, o2, o3;
-    philox_block((j + 1u) >> 1, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
-    const double a = u64_to_unit(o0, o1), b = u64_to_unit(o2, o3);
-    const bool odd = (j & 1u) != 0u;
-    u1 = odd ? spare : a;
-    u2 = odd ? a : b;
-    spare = b;
+    philox_block(j >> 1, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
+    u1 = u64_to_unit(o0, o1);
+    u2 = u64_to_unit(o2, o3);
   }
 };
 
@@ -167,6 +163,8 @@ struct Rng {
 __shared__ double S_x[MCS_MAXNE], S_ux[MCS_MAXNE], S_uz[MCS_MAXNE], S_ut[MCS_MAXNE], S_gsf[MCS_MAXNE], S_gef[MCS_MAXNE],
     S_bt[MCS_MAXNE], S_bsin[MCS_MAXNE], S_bcos[MCS_MAXNE], S_gd[MCS_MAXNE];
 __shared__ double S_fl[3 * MCS_MAXNE];      // pxx | pxz | energy flux staging, stride MCS_MAXNE
+__shared__ double S_eff[2][MCS_PSD_MAX + 1]; // esc_energy_eff | esc_num_eff of this ion: one entry per momentum bin, i.e. ONE
+                                            // address for a population of replicas (a global atomic there serialises at ~6 ns)
 __shared__ double S_tc[MCS_NA_C];           // time cuts
 __shared__ int S_nc[MCS_MAXNE];             // num_crossings staging
 // Deferred zone-crossing tallies: a lane that crossed a zone boundary does NOT run the
@@ -541,7 +539,7 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
 struct Retro {
   double ptot, pb, pperp, gam, phi, gyro_denom, acctime, tcut_next;
   int tcut, n_retro;
-  uint32_t rng_n; double rng_spare;
+  uint32_t rng_n;
   bool lose_pt;
 };
 
@@ -550,7 +548,7 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
   const auto& P = a->P;
   const int ng = P.n_grid;
   const double aa = a->aa;
-  Rng rng; rng.k0 = k0; rng.k1 = k1; rng.n = r.rng_n; rng.spare = r.rng_spare;
+  Rng rng; rng.k0 = k0; rng.k1 = k1; rng.n = r.rng_n;
   const double xn_per = MCS_RETRO_XN_PER;
   const double phi_step = TWOPI_ / xn_per;
   const double t_step_fac = TWOPI_ * aa * MP_ * CC_ * r.gyro_denom / xn_per;
@@ -614,7 +612,7 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
     }
     if (x_PT < prp) break;
   }
-  r.rng_n = rng.n; r.rng_spare = rng.spare;
+  r.rng_n = rng.n;
   return r;
 }
 
@@ -687,8 +685,10 @@ __device__ MCS_COLD Mom do_energy_transfer(CK* a, int i_grid, int i_grid_old, do
 }
 
 // src/particle_finish.jl:46-107 (with D2).  Zone properties of zone ig3.
+// `off`/`val` (optional): the escape-spectrum tally is handed back instead of being added, so that the caller can
+// combine the lanes of a wave that hit the same bin (see drain_events)
 __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_pf, double p_perp, double gam_pf,
-                                             double phi, double weight, int ig3) {
+                                             double phi, double weight, int ig3, long long* off = nullptr, double* val = nullptr) {
   const double aa = a->aa;
   const double m = aa * MP_;
   const double E0 = m * (CC_ * CC_);
@@ -702,17 +702,19 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
   const long long pm = MCS_PSD_MAX + 1;
   const int ion = a->i_ion - 1;
   if (i_reason == 1) {
-    tadd(a, a->L.esc_psd_down + ip + pm * jth, weight * wf);
+    if (off) { *off = a->L.esc_psd_down + ip + pm * jth; *val = weight * wf; }
+    else tadd(a, a->L.esc_psd_down + ip + pm * jth, weight * wf);
   } else if (i_reason == 2) {
     sadd(4, weight);
-    tadd(a, a->L.esc_psd_up + ip + pm * jth, weight * wf);
+    if (off) { *off = a->L.esc_psd_up + ip + pm * jth; *val = weight * wf; }
+    else tadd(a, a->L.esc_psd_up + ip + pm * jth, weight * wf);
     const bool rel = (gam_sk - 1) >= MCS_E_REL_PT;
     const double E_kin = rel ? (gam_sk - 1) * E0 : ptot_sk * ptot_sk / (2 * m);
     const double eadd = E_kin * weight;
     sadd(5, __builtin_fabs(px) * weight);
     sadd(6, eadd);
-    tadd(a, a->L.esc_energy_eff + ip + pm * ion, eadd);
-    tadd(a, a->L.esc_num_eff + ip + pm * ion, weight);
+    ladd_f64(&S_eff[0][ip], eadd);
+    ladd_f64(&S_eff[1][ip], weight);
   }
 }
 
@@ -754,11 +756,11 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
       Retro r;
       r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
       r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = tcut_next_of(a, h, p.tcut); r.tcut = p.tcut;
-      r.n_retro = p.n_retro; r.rng_n = rng.n; r.rng_spare = rng.spare; r.lose_pt = false;
+      r.n_retro = p.n_retro; r.rng_n = rng.n; r.lose_pt = false;
       r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut = r.tcut;
-      p.n_retro = r.n_retro; rng.n = r.rng_n; rng.spare = r.rng_spare; lose_pt = r.lose_pt;
+      p.n_retro = r.n_retro; rng.n = r.rng_n; lose_pt = r.lose_pt;
       p.flags |= F_RS | F_RM;          // radiative losses inside the walk change ptot_pf / gam_pf
       if (lose_pt) i_return = 0;
       p.x = p.prp;
@@ -1221,16 +1223,33 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
   while (cnt >= 64u || (all && cnt > 0u)) {
     const unsigned take = cnt < 64u ? cnt : 64u;
     const unsigned base = cnt - take;
+    long long foff = -1; double fval = 0.0;
     if (lane < take) {
       const unsigned e = base + lane;
       const uint32_t u = S_evu[wv][e];
       if (u >> 28) {     // a finished particle (particle_finish!): reason in bits 25-27
         particle_finish(a, s, (int)((u >> 25) & 7u), S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][3][e], S_evf[wv][4][e],
-                        S_evf[wv][5][e], (int)((u >> 16) & 0xffu));
+                        S_evf[wv][5][e], (int)((u >> 16) & 0xffu), &foff, &fval);
       } else {
         flux_tally(a, s, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
                    S_evf[wv][6][e], S_evf[wv][7][e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu),
                    ((u >> 24) & 1u) != 0u);
+      }
+    }
+    // the escape-spectrum tallies of the batch.  A population of replicas of ONE saved particle that leave before
+    // their first scatter hits ONE bin a million times, and a global atomic on one address serialises at ~12 ns
+    // (12 ms per launch, measured): when every tally of the batch goes to the same bin the wave adds them up first.
+    const unsigned long long vm = __builtin_amdgcn_ballot_w64(foff >= 0);
+    if (vm != 0ull) {
+      const int first = __ffsll((long long)vm) - 1;
+      const long long off0 = __shfl(foff, first);
+      if (__builtin_amdgcn_ballot_w64(foff >= 0 && foff != off0) == 0ull) {
+        double sum = foff >= 0 ? fval : 0.0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if ((int)lane == first) tadd(a, off0, sum);
+      } else if (foff >= 0) {
+        tadd(a, foff, fval);
       }
     }
     cnt = base;
@@ -1263,7 +1282,7 @@ __device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& 
                                             double phi_prev) {
   const double v[30] = {p.weight, p.ptot_pf, p.pb_pf, p.p_perp, p.gam_pf, p.x, p.x_old, p.phi, p.prp, p.acctime, p.xn_per, p.dphi,
                         p.gyro_denom, p.gyro_rad, p.gyro_rad_tot, p.gyro_period, p.t_step, p.rp_val, p.cm_val, p.rg_val, p.x_dt,
-                        p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, rng.spare, phi_prev};
+                        p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, phi_prev, 0.0};
 #pragma unroll
   for (int j = 0; j < 30; ++j) mb[j * STRIDE] = v[j];
   mb[30 * STRIDE] = __longlong_as_double(k);
@@ -1283,9 +1302,10 @@ __device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, lo
     if (COHERENT) return __hip_atomic_load(mb + j * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return mb[j * STRIDE];
   };
+  double unused__;
   double* const d[30] = {&p.weight, &p.ptot_pf, &p.pb_pf, &p.p_perp, &p.gam_pf, &p.x, &p.x_old, &p.phi, &p.prp, &p.acctime, &p.xn_per,
                          &p.dphi, &p.gyro_denom, &p.gyro_rad, &p.gyro_rad_tot, &p.gyro_period, &p.t_step, &p.rp_val, &p.cm_val,
-                         &p.rg_val, &p.x_dt, &p.t_ev, &p.z_gsf, &p.z_bcos, &p.z_ux, &p.z_gef, &p.z_lo, &p.z_hi, &rng.spare, &phi_prev};
+                         &p.rg_val, &p.x_dt, &p.t_ev, &p.z_gsf, &p.z_bcos, &p.z_ux, &p.z_gef, &p.z_lo, &p.z_hi, &phi_prev, &unused__};
 #pragma unroll
   for (int j = 0; j < 30; ++j) *d[j] = LD(j);
   k = __double_as_longlong(LD(30));
@@ -1338,6 +1358,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     S_gd[i] = 1 / (a->zzq * bt);
   }
   for (int i = threadIdx.x; i < 3 * MCS_MAXNE; i += blockDim.x) S_fl[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * (MCS_PSD_MAX + 1); i += blockDim.x) (&S_eff[0][0])[i] = 0.0;
   for (int i = threadIdx.x; i < ntc; i += blockDim.x) S_tc[i] = a->tb.tcuts[i];
   for (int i = threadIdx.x; i < MCS_MAXNE; i += blockDim.x) S_nc[i] = 0;
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
@@ -1715,7 +1736,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF_TAIL
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
-    if (parking && !exhausted) n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));
+    n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));     // (unconditional: no branch in the common pass)
     // ---- the common pass, for every lane (idle lanes compute on stale state; nothing is stored)
     p.helix += 1;
     if (!h.dont_scatter) scattering(rng, p, kc);
@@ -1768,6 +1789,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
     const int c = S_nc[i];
     if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
+  }
+  for (int i = threadIdx.x; i <= MCS_PSD_MAX; i += blockDim.x) {
+    const long long o = i + (long long)(MCS_PSD_MAX + 1) * (a->i_ion - 1);
+    const double e = S_eff[0][i], w = S_eff[1][i];
+    if (e != 0.0) gadd_f64(&a->T[a->L.esc_energy_eff + o], e);
+    if (w != 0.0) gadd_f64(&a->T[a->L.esc_num_eff + o], w);
   }
 }
 
