@@ -163,6 +163,7 @@ struct Rng {
 __shared__ double S_x[MCS_MAXNE], S_ux[MCS_MAXNE], S_uz[MCS_MAXNE], S_ut[MCS_MAXNE], S_gsf[MCS_MAXNE], S_gef[MCS_MAXNE],
     S_bt[MCS_MAXNE], S_bsin[MCS_MAXNE], S_bcos[MCS_MAXNE], S_gd[MCS_MAXNE];
 __shared__ double S_fl[3 * MCS_MAXNE];      // pxx | pxz | energy flux staging, stride MCS_MAXNE
+__shared__ double S_wc[MCS_NA_C];            // weight_coupled of this ion: one address per time cut, hit by every particle that passes it
 __shared__ double S_eff[2][MCS_PSD_MAX + 1]; // esc_energy_eff | esc_num_eff of this ion: one entry per momentum bin, i.e. ONE
                                             // address for a population of replicas (a global atomic there serialises at ~6 ns)
 __shared__ double S_tc[MCS_NA_C];           // time cuts
@@ -443,7 +444,7 @@ __device__ __forceinline__ double radiation_loss(double B2, double pp, double dt
 // src/cuts.jl:149-162 plus the caller's `tcut_curr += 1` (particle_loop.jl:352-358, prob_return.jl:297-304)
 __device__ MCS_COLD void tcut_track(CK* a, int tcut_curr, double weight, double ptot_pf) {
   const int ion = a->i_ion - 1;
-  tadd(a, a->L.weight_coupled + (tcut_curr - 1) + (long long)MCS_NA_C * ion, weight);
+  ladd_f64(&S_wc[tcut_curr - 1], weight);
   const int i_pt = bin_momentum(a, ptot_pf);
   tadd(a, a->L.spectra_coupled + i_pt + (long long)(MCS_PSD_MAX + 1) * ((tcut_curr - 1) + (long long)MCS_NA_C * ion), weight);
 }
@@ -700,7 +701,6 @@ __device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_p
   if (ptot_sk > __builtin_fabs(MCS_SPIKE_AWAY * px)) wf = gam_sk * m * MCS_SPIKE_AWAY / ptot_sk;
   else wf = gam_sk * (m / __builtin_fabs(px));
   const long long pm = MCS_PSD_MAX + 1;
-  const int ion = a->i_ion - 1;
   if (i_reason == 1) {
     if (off) { *off = a->L.esc_psd_down + ip + pm * jth; *val = weight * wf; }
     else tadd(a, a->L.esc_psd_down + ip + pm * jth, weight * wf);
@@ -1359,6 +1359,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   }
   for (int i = threadIdx.x; i < 3 * MCS_MAXNE; i += blockDim.x) S_fl[i] = 0.0;
   for (int i = threadIdx.x; i < 2 * (MCS_PSD_MAX + 1); i += blockDim.x) (&S_eff[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < MCS_NA_C; i += blockDim.x) S_wc[i] = 0.0;
   for (int i = threadIdx.x; i < ntc; i += blockDim.x) S_tc[i] = a->tb.tcuts[i];
   for (int i = threadIdx.x; i < MCS_MAXNE; i += blockDim.x) S_nc[i] = 0;
   if (threadIdx.x <= MCS_IC_COUNT) g_ctr[threadIdx.x] = 0u;
@@ -1789,6 +1790,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
     const int c = S_nc[i];
     if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
+  }
+  for (int i = threadIdx.x; i < MCS_NA_C; i += blockDim.x) {
+    const double w = S_wc[i];
+    if (w != 0.0) gadd_f64(&a->T[a->L.weight_coupled + i + (long long)MCS_NA_C * (a->i_ion - 1)], w);
   }
   for (int i = threadIdx.x; i <= MCS_PSD_MAX; i += blockDim.x) {
     const long long o = i + (long long)(MCS_PSD_MAX + 1) * (a->i_ion - 1);
