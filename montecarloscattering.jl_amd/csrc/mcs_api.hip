@@ -27,6 +27,7 @@ hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* 
                                int n_bins, const double* bin_ptot, const double* bin_weight, const long long* bin_start,
                                hipStream_t st);
 hipError_t mcs_launch_fill(double* p, long long n, double v, hipStream_t st);
+hipError_t mcs_launch_fold_replicas(double* dst, double* rep, long long n, int n_rep, hipStream_t st);
 hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStream_t st);
 hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b, double* out, hipStream_t st);
 hipError_t mcs_launch_dndp_cr(const mcs_params* P, const double* psd, const double* gam_sf, const double* ux, const double* tabs,
@@ -75,6 +76,9 @@ struct mcs_ctx {
   long long f_cap = 0;
   // scan scratch
   unsigned int* d_bcounts = nullptr; unsigned long long* d_boffs = nullptr; long long* d_src = nullptr; long long scan_cap = 0;
+  double* d_therm_rep = nullptr;               // replicas of therm_sf | therm_pf (KArgs::therm_rep)
+  bool therm_dirty = false;                    // a launch may have added to the replicas since the last fold
+  bool therm_replicas = true;                  // MCS_THERM_REPLICAS_OFF=1: tally straight into T
   double* d_park = nullptr;                    // park buffer of the transport kernel (KArgs::park)
   bool park = true;                           // MCS_PARK=0: no parking (A/B measurements)
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
@@ -203,6 +207,16 @@ int download_soa(mcs_ctx* c, const PopBuf& b, long long n, mcs_soa* h) {
 
 extern "C" {
 
+// The thermal histograms are tallied into MCS_THERM_REPLICAS private copies (mcs_device.h); everything that reads
+// or rewrites the tally buffer folds them in first.
+static int fold_replicas(mcs_ctx* c) {
+  if (!c->therm_dirty || !c->d_therm_rep) return 0;
+  const long long n = 2 * c->L.psd_stride_zone * c->P.n_grid;
+  HIPCHK(mcs_launch_fold_replicas(c->d_T + c->L.therm_sf, c->d_therm_rep, n, MCS_THERM_REPLICAS, c->stream));
+  c->therm_dirty = false;
+  return 0;
+}
+
 int mcs_abi_version(void) { return MCS_ABI_VERSION; }
 const char* mcs_last_error(void) { return g_err.c_str(); }
 int mcs_get_layout(const mcs_params* p, mcs_layout* out) { mcs_tally_layout(p, out); return 0; }
@@ -235,6 +249,12 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
+  { const char* e = std::getenv("MCS_THERM_REPLICAS_OFF"); c->therm_replicas = !(e && e[0] == '1'); }
+  if (c->therm_replicas) {
+    const size_t nrep = (size_t)MCS_THERM_REPLICAS * 2 * c->L.psd_stride_zone * p->n_grid;
+    HIPCHK(hipMalloc((void**)&c->d_therm_rep, nrep * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_therm_rep, 0, nrep * sizeof(double), c->stream));
+  }
   HIPCHK(hipMalloc((void**)&c->d_park, (size_t)MCS_PARK_WAVES * MCS_PARK_SLOTS * MCS_PARK_WORDS * sizeof(double)));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
   HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
@@ -256,7 +276,7 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park,
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park, c->d_therm_rep,
                   c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
@@ -268,10 +288,17 @@ int mcs_destroy(mcs_ctx* c) {
   return 0;
 }
 
-int mcs_sync(mcs_ctx* c) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+int mcs_sync(mcs_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  if (fold_replicas(c)) return 1;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
 
 int mcs_bind_tallies(mcs_ctx* c, double* dev_f64, int64_t n_f64, int64_t* dev_i64, int64_t n_i64) {
   HIPCHK(hipSetDevice(c->device));
+  if (fold_replicas(c)) return 1;
+  HIPCHK(hipStreamSynchronize(c->stream));
   if (dev_f64) {
     if (n_f64 < c->L.total) return fail("mcs_bind_tallies: f64 buffer smaller than layout.total");
     if (c->own_T && c->d_T) (void)hipFree(c->d_T);
@@ -374,6 +401,7 @@ int mcs_begin_species(mcs_ctx* c, int i_iter, int i_ion, double aa, double zz, d
   if (!(aa > 0) || zz == 0) return fail("mcs_begin_species: aa must be > 0 and zz != 0");
   c->i_iter = i_iter; c->i_ion = i_ion; c->aa = aa; c->zzq = zz * MCS_QCGS; c->m = aa * MCS_MP; c->mc = c->m * MCS_C;
   c->pmax_cutoff = pmax_cutoff; c->density = density; c->ewf = ewf;
+  if (fold_replicas(c)) return 1;      // (the previous species' replicas, before its histograms are cleared)
   const long long npsd = c->L.psd_stride_zone * P.n_grid;
   const long long pm = MCS_PSD_MAX + 1;
   if (fill(c, c->L.psd, npsd, MCS_FLOOR) || fill(c, c->L.therm_sf, 2 * npsd, 0.0) ||
@@ -515,6 +543,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
   a.tail_merge = c->tail_merge ? 1 : 0;
   a.park = c->park ? c->d_park : nullptr;
+  a.therm_rep = c->d_therm_rep;
   a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
 
   const int threads = c->threads;
@@ -532,7 +561,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                      !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
-  if (n > 0) HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
+  if (n > 0) { HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream)); c->therm_dirty = true; }
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   unsigned long long ns = 0;
   HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
@@ -575,6 +604,7 @@ int mcs_run_pcut_host(mcs_ctx* c, int i_pcut, int64_t n_pts_use, int64_t i_prt_o
 
 int mcs_read_tallies(mcs_ctx* c, double* host_f64, int64_t* host_i64) {
   HIPCHK(hipSetDevice(c->device));
+  if (fold_replicas(c)) return 1;
   if (host_f64) HIPCHK(hipMemcpyAsync(host_f64, c->d_T, (size_t)c->L.total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (host_i64) HIPCHK(hipMemcpyAsync(host_i64, c->d_I, (size_t)mcs_i64_total(&c->P) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -582,6 +612,7 @@ int mcs_read_tallies(mcs_ctx* c, double* host_f64, int64_t* host_i64) {
 }
 int mcs_write_tallies(mcs_ctx* c, const double* host_f64, const int64_t* host_i64) {
   HIPCHK(hipSetDevice(c->device));
+  if (fold_replicas(c)) return 1;
   if (host_f64) HIPCHK(hipMemcpyAsync(c->d_T, host_f64, (size_t)c->L.total * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (host_i64) HIPCHK(hipMemcpyAsync(c->d_I, host_i64, (size_t)mcs_i64_total(&c->P) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -630,6 +661,7 @@ static int consumers_ready(mcs_ctx* c, const mcs_consumer_in* in, const char* wh
 int mcs_dndp_cr(mcs_ctx* c, const mcs_consumer_in* in, double* dNdp, int64_t* diag) {
   HIPCHK(hipSetDevice(c ? c->device : 0));
   if (consumers_ready(c, in, "mcs_dndp_cr")) return 1;
+  if (fold_replicas(c)) return 1;
   if (!in->mom_log_cgs || !in->mom_edge_cgs || !in->cos_edge || !in->zone_pop || !dNdp) return fail("mcs_dndp_cr: null table");
   const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
   std::vector<double> h((size_t)(2 * NM + NT + ng));
@@ -652,6 +684,7 @@ int mcs_dndp_cr(mcs_ctx* c, const mcs_consumer_in* in, double* dNdp, int64_t* di
 int mcs_thermo_calcs(mcs_ctx* c, const mcs_consumer_in* in, double* P_par, double* P_perp, double* energy_density) {
   HIPCHK(hipSetDevice(c ? c->device : 0));
   if (consumers_ready(c, in, "mcs_thermo_calcs")) return 1;
+  if (fold_replicas(c)) return 1;
   if (!in->cos_center || !in->pt_center || !in->zone_pop || !in->density_loc || !in->cold_pressure || !P_par || !P_perp || !energy_density)
     return fail("mcs_thermo_calcs: null table");
   const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;

@@ -46,9 +46,15 @@ struct KArgs {
   unsigned long long* n_saved;
   int32_t *f_reason, *f_helix, *f_retro;
   double *f_ptot, *f_x;
+  double* therm_rep;         // MCS_THERM_REPLICAS private copies of the therm_sf | therm_pf histograms (null: tally into T)
   double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
 };
+
+// Replicas of the thermal-crossing histograms.  Cold particles pile their crossings onto a few cache lines, and a
+// memory-side fp64 atomic takes ~12 ns per line: the first pcut of a species ran at the atomic rate.  Each block adds
+// to replica blockIdx % R; the host folds the replicas into T before anything reads the tallies.
+#define MCS_THERM_REPLICAS 16
 
 // particles waiting for their full Code Blocks, per wave (see the park logic of the transport kernel)
 #define MCS_PARK_SLOTS 16

@@ -263,3 +263,17 @@ hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b
 }
 
 }  // extern "C"
+
+// Fold the replicas of the thermal histograms into the tally buffer and clear them (see MCS_THERM_REPLICAS).
+extern "C" __global__ void mcs_k_fold_replicas(double* __restrict__ dst, double* __restrict__ rep, long long n, int n_rep) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int r = 0; r < n_rep; ++r) { s += rep[(long long)r * n + i]; rep[(long long)r * n + i] = 0.0; }
+    if (s != 0.0) dst[i] += s;
+  }
+}
+extern "C" hipError_t mcs_launch_fold_replicas(double* dst, double* rep, long long n, int n_rep, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  mcs_k_fold_replicas<<<2048, 256, 0, st>>>(dst, rep, n, n_rep);
+  return hipGetLastError();
+}

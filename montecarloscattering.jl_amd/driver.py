@@ -179,6 +179,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
 
             # species end: merge the partial tallies of all ranks (C1)
             if multi and dev_t is not None:
+                backend.sync()          # the bound tensors are complete after mcs_sync (it folds the tally replicas in)
                 tf, ti = dev_t
                 if not is_root:   # every rank carried a full copy of the received-energy pool
                     tview(tf, "energy_recv_pool").zero_()

@@ -159,6 +159,10 @@ class HipBackend:
         return int(nn.value)
 
     # -- tallies
+    def sync(self):
+        """Everything launched so far is done and the bound tally tensors are complete (replicas folded in)."""
+        self._chk(self.lib.mcs_sync(self.h))
+
     def read_tallies(self):
         f = np.zeros(self.layout.total)
         i = np.zeros(self.layout.n_i64, dtype=np.int64)
