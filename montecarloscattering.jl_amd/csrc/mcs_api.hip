@@ -76,9 +76,10 @@ struct mcs_ctx {
   long long f_cap = 0;
   // scan scratch
   unsigned int* d_bcounts = nullptr; unsigned long long* d_boffs = nullptr; long long* d_src = nullptr; long long scan_cap = 0;
-  double* d_therm_rep = nullptr;               // replicas of therm_sf | therm_pf (KArgs::therm_rep)
-  bool therm_dirty = false;                    // a launch may have added to the replicas since the last fold
-  bool therm_replicas = true;                  // MCS_THERM_REPLICAS_OFF=1: tally straight into T
+  double* d_tally_rep = nullptr;               // replicas of the histograms at the head of the tally buffer (KArgs::tally_rep)
+  long long rep_n = 0;                         // doubles per replica (0: no replicas)
+  bool rep_dirty = false;                    // a launch may have added to the replicas since the last fold
+  bool tally_replicas = true;                  // MCS_TALLY_REPLICAS_OFF=1: tally straight into T
   double* d_park = nullptr;                    // park buffer of the transport kernel (KArgs::park)
   bool park = true;                           // MCS_PARK=0: no parking (A/B measurements)
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
@@ -207,13 +208,12 @@ int download_soa(mcs_ctx* c, const PopBuf& b, long long n, mcs_soa* h) {
 
 extern "C" {
 
-// The thermal histograms are tallied into MCS_THERM_REPLICAS private copies (mcs_device.h); everything that reads
+// The thermal histograms are tallied into MCS_TALLY_REPLICAS private copies (mcs_device.h); everything that reads
 // or rewrites the tally buffer folds them in first.
 static int fold_replicas(mcs_ctx* c) {
-  if (!c->therm_dirty || !c->d_therm_rep) return 0;
-  const long long n = 2 * c->L.psd_stride_zone * c->P.n_grid;
-  HIPCHK(mcs_launch_fold_replicas(c->d_T + c->L.therm_sf, c->d_therm_rep, n, MCS_THERM_REPLICAS, c->stream));
-  c->therm_dirty = false;
+  if (!c->rep_dirty || !c->d_tally_rep) return 0;
+  HIPCHK(mcs_launch_fold_replicas(c->d_T, c->d_tally_rep, c->rep_n, MCS_TALLY_REPLICAS, c->stream));
+  c->rep_dirty = false;
   return 0;
 }
 
@@ -249,11 +249,12 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
-  { const char* e = std::getenv("MCS_THERM_REPLICAS_OFF"); c->therm_replicas = !(e && e[0] == '1'); }
-  if (c->therm_replicas) {
-    const size_t nrep = (size_t)MCS_THERM_REPLICAS * 2 * c->L.psd_stride_zone * p->n_grid;
-    HIPCHK(hipMalloc((void**)&c->d_therm_rep, nrep * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->d_therm_rep, 0, nrep * sizeof(double), c->stream));
+  { const char* e = std::getenv("MCS_TALLY_REPLICAS_OFF"); c->tally_replicas = !(e && e[0] == '1'); }
+  if (c->tally_replicas) {
+    c->rep_n = c->L.esc_psd_down + (long long)(MCS_PSD_MAX + 1) * (MCS_PSD_MAX + 1);     // psd .. esc_psd_down: the head of the layout
+    const size_t nrep = (size_t)MCS_TALLY_REPLICAS * (size_t)c->rep_n;
+    HIPCHK(hipMalloc((void**)&c->d_tally_rep, nrep * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));
   }
   HIPCHK(hipMalloc((void**)&c->d_park, (size_t)MCS_PARK_WAVES * MCS_PARK_SLOTS * MCS_PARK_WORDS * sizeof(double)));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -276,7 +277,7 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park, c->d_therm_rep,
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park, c->d_tally_rep,
                   c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
@@ -543,7 +544,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
   a.tail_merge = c->tail_merge ? 1 : 0;
   a.park = c->park ? c->d_park : nullptr;
-  a.therm_rep = c->d_therm_rep;
+  a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
   a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
 
   const int threads = c->threads;
@@ -561,7 +562,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                      !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
-  if (n > 0) { HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream)); c->therm_dirty = true; }
+  if (n > 0) { HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream)); c->rep_dirty = true; }
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   unsigned long long ns = 0;
   HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));

@@ -289,7 +289,12 @@ __device__ __forceinline__ void cnt(CK* a, int which, unsigned int v = 1u) {
                                __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void sadd(int which, double v) { ladd_f64(&g_sc[which], v); }
-__device__ __forceinline__ void tadd(CK* a, long long off, double v) { gadd_f64(&a->T[off], v); }
+// a tally: into this block's replica of the histograms at the head of the buffer (see MCS_TALLY_REPLICAS), else into T
+__device__ __forceinline__ void tadd(CK* a, long long off, double v) {
+  double* base = a->T;
+  if (off < a->rep_n) base = a->tally_rep + (long long)(blockIdx.x % MCS_TALLY_REPLICAS) * a->rep_n;
+  gadd_f64(&base[off], v);
+}
 
 // src/get_psd_bins.jl:16-39
 __device__ __forceinline__ int bin_momentum(CK* a, double ptot_sk) {
@@ -513,12 +518,8 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
       tadd(a, a->L.psd + i_pt + a->L.psd_stride_tht * jth + a->L.psd_stride_zone * (long long)(i - 1), tw);
     } else {
       if (P.track_thermal) {   // A9: bin the thermal crossing instead of appending to a list
-        // this block's private copy of the two thermal histograms (see MCS_THERM_REPLICAS), addressed with T's offsets
-        double* const therm_base = a->therm_rep
-            ? a->therm_rep + (long long)(blockIdx.x % MCS_THERM_REPLICAS) * (2 * a->L.psd_stride_zone * P.n_grid) - a->L.therm_sf
-            : a->T;
         if (!have_sf) { k_sf = bin_momentum(a, ptot_sk); j_sf = bin_angle(a, px, ptot_sk); have_sf = true; }
-        gadd_f64(&therm_base[a->L.therm_sf + k_sf + a->L.psd_stride_tht * j_sf + a->L.psd_stride_zone * (long long)(i - 1)], tw);
+        tadd(a, a->L.therm_sf + k_sf + a->L.psd_stride_tht * j_sf + a->L.psd_stride_zone * (long long)(i - 1), tw);
         const double gam = S_gsf[i];
         const double beta = S_ux[i] / CC_;
         const double E0 = a->m * CC_ * CC_;
@@ -529,7 +530,7 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
         if (__builtin_fabs(px_Xf) > pt_Xf) px_Xf = __builtin_copysign(pt_Xf, px_Xf);
         const int k_pf = bin_momentum(a, pt_Xf);
         const int j_pf = bin_angle(a, px_Xf, pt_Xf);
-        gadd_f64(&therm_base[a->L.therm_pf + k_pf + a->L.psd_stride_tht * j_pf + a->L.psd_stride_zone * (long long)(i - 1)], tw);
+        tadd(a, a->L.therm_pf + k_pf + a->L.psd_stride_tht * j_pf + a->L.psd_stride_zone * (long long)(i - 1), tw);
       }
       ladd_i32(&S_nc[i - 1], 1);
     }
