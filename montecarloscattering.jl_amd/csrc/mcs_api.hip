@@ -251,7 +251,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
   { const char* e = std::getenv("MCS_TALLY_REPLICAS_OFF"); c->tally_replicas = !(e && e[0] == '1'); }
   if (c->tally_replicas) {
-    c->rep_n = c->L.esc_psd_down + (long long)(MCS_PSD_MAX + 1) * (MCS_PSD_MAX + 1);     // psd .. esc_psd_down: the head of the layout
+    c->rep_n = c->L.total;     // the whole tally buffer: the three big histograms are 99 % of it
     const size_t nrep = (size_t)MCS_TALLY_REPLICAS * (size_t)c->rep_n;
     HIPCHK(hipMalloc((void**)&c->d_tally_rep, nrep * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));

@@ -46,13 +46,13 @@ struct KArgs {
   unsigned long long* n_saved;
   int32_t *f_reason, *f_helix, *f_retro;
   double *f_ptot, *f_x;
-  double* tally_rep;         // MCS_TALLY_REPLICAS private copies of T[0 .. rep_n): psd | therm_sf | therm_pf | esc_psd_up | esc_psd_down
-  long long rep_n;           // (null / 0: tally into T)
+  double* tally_rep;         // MCS_TALLY_REPLICAS private copies of T[0 .. rep_n) for the per-event tallies (the LDS-staged
+  long long rep_n;           // sums are flushed into T itself); null / 0: tally into T
   double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
 };
 
-// Replicas of the big histograms (the head of the tally buffer).  Particles of one population pile their tallies onto
+// Replicas of the tally buffer.  Particles of one population pile their tallies onto
 // a few cache lines -- cold particles most of all -- and a memory-side fp64 atomic takes ~12 ns per line: the first
 // pcut of a species ran at the atomic rate (21 ms instead of 6).  Each block adds to replica blockIdx % R; the host
 // folds the replicas into T before anything reads the tallies (mcs_sync, mcs_read_tallies, the consumers, ...).
