@@ -119,11 +119,10 @@ __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t 
 }
 
 __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
-  // (double)(u64 >> 11) * 2^-53, spelled so that it costs 5 instructions: the 53-bit integer is
-  // h * 2^32 + l with h < 2^21; both conversions, the fma and the scaling are exact.
-  const uint32_t h = hi >> 11;
-  const uint32_t l = (hi << 21) | (lo >> 11);
-  return __builtin_ldexp(__builtin_fma((double)h, 4294967296.0, (double)l), -53);
+  // (double)(u64 >> 11) * 2^-53: the 53-bit integer is hi * 2^21 + (lo >> 11), so the value is
+  // hi * 2^-32 + (lo >> 11) * 2^-53 -- two exact conversions, an exact scaling and an fma whose result is
+  // representable, hence exact: one shift, two v_cvt, a multiply and an fma.
+  return __builtin_fma((double)hi, 0x1.0p-32, (double)(lo >> 11) * 0x1.0p-53);
 }
 
 // Per-particle stream: draw j -> words (2*(j&1), 2*(j&1)+1) of block j>>1.  The draw index is even wherever
