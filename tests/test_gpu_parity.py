@@ -233,7 +233,8 @@ def test_specialised_and_general_kernel_agree(monkeypatch):
 
 def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
     """K1 moves particles between lanes: a lane that needs the full Code Blocks parks its particle until the next
-    refill (MCS_PARK), and sparse waves of a block merge after the work counter is exhausted (MCS_TAIL_MERGE).
+    refill (MCS_PARK), and sparse waves of a block merge after the work counter is exhausted (MCS_TAIL_MERGE); the
+    tallies go to per-block replicas that are folded into the buffer when it is read (MCS_TALLY_REPLICAS_OFF).
     The state and the RNG stream travel with the particle: with both switched off the particles are bit-identical.
     Few blocks, so that every lane is refilled many times and both mechanisms have work."""
     N = 6000
@@ -242,6 +243,7 @@ def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
     for on in ("1", "0"):
         monkeypatch.setenv("MCS_PARK", on)
         monkeypatch.setenv("MCS_TAIL_MERGE", on)
+        monkeypatch.setenv("MCS_TALLY_REPLICAS_OFF", "0" if on == "1" else "1")   # 16 tally replicas folded at read time
         hb = hip_backend(prob)
         hb.set_launch(4, 256)
         start_species(hb, prob)
