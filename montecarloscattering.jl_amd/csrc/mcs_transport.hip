@@ -1481,7 +1481,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   unsigned refill_at = MCS_REFILL_MIN;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   p.npush = 0;
-  for (;;) {
+  bool done = false;
+  while (!done) {
     ev_pending += (unsigned)(__popcll(__builtin_amdgcn_ballot_w64(p.npush > 0)) + __popcll(__builtin_amdgcn_ballot_w64(p.npush > 1)));
     p.npush = 0;
     // ---- housekeeping behind ONE scalar branch: records to tally, idle lanes to refill, nothing left
@@ -1590,10 +1591,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         }
       }
       if (exhausted) refill_at = n_parked > 0u ? 1u : 64u;
-      if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
-        if (exhausted && n_parked == 0u) break;
-        continue;
-      }
+      // nothing left: the loop ends after this pass (which computes on idle lanes and stores nothing) -- no jump
+      // out of the middle of the loop, which costs the common pass a branch and half a dozen register copies
+      done = (__builtin_amdgcn_ballot_w64(active) == 0ull) & exhausted & (n_parked == 0u);
     }
     {
       [[maybe_unused]] const int na__ = __popcll(__builtin_amdgcn_ballot_w64(active));
