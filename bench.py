@@ -94,7 +94,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # MCS_BENCH_FORCE_COMM=1 (rehearsal, never set by the driver): run the multi-rank code path -- RCCL process
+    # group, bound torch tally tensors, all-gather(n_saved) per pcut, in-place all-reduce -- with whatever world size
+    # there is, 1 included: a one-GPU box cannot host two RCCL ranks, but it can run that path once.
+    force_comm = os.environ.get("MCS_BENCH_FORCE_COMM") == "1"
+    if world > 1 or force_comm:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -105,9 +109,9 @@ def main():
     n_itrs = args.steps + args.warmup
     cfg = mcs.inputs.Config(N_PTS_INJ=n_global, N_PTS_PCUT=n_global, N_PTS_PCUT_HI=n_global, num_iterations=n_itrs)
     prob = mcs.inputs.build_problem(cfg)
-    be = hip_backend.HipBackend(local, torch_tallies=world > 1)
+    be = hip_backend.HipBackend(local, torch_tallies=world > 1 or force_comm)
     be.create(prob)
-    comm = mcs.driver.Comm(world > 1, dev)
+    comm = mcs.driver.Comm(world > 1 or force_comm, dev)
 
     def barrier():
         torch.cuda.synchronize()

@@ -104,7 +104,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     per_species = []
     # rank > 0 keeps only its local partial sums: everything it contributes is a delta
     is_root = comm.rank == 0
-    multi = comm.world > 1
+    multi = comm.enabled          # (a forced one-rank group runs the multi-rank path too: bench.py MCS_BENCH_FORCE_COMM)
     G_f = G_i = None
     # Live device tensors of the tallies (HIP backend with torch_tallies): the multi-GPU merge
     # then runs in place on the device (RCCL all-reduce, no host round trip).  Otherwise
