@@ -69,7 +69,7 @@ class Comm:
         t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
         out = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
-        return [int(o.item()) for o in out]
+        return [int(x) for x in torch.cat(out).tolist()]      # one device-to-host copy, not one per rank
 
     def all_reduce_sum_(self, tensor):
         if self.enabled:
