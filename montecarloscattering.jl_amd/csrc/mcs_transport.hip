@@ -46,7 +46,8 @@
 #define MCS_WAVES_PER_SIMD 2
 #endif
 #ifndef MCS_REFILL_MIN
-#define MCS_REFILL_MIN 8        // idle lanes a wave collects before it claims new particles (measured: 1 -> 630 ms, 2 -> 617, 4 -> 615, 8 -> 610, 16 -> 611)
+#define MCS_REFILL_MIN 12       // idle lanes a wave collects before it claims new particles: a refill stalls the wave for a memory latency,
+                                // and parked particles resume in batches of that size (final kernel: 6 -> 458 ms, 8 -> 451, 12 -> 442, 16 -> 444)
 #endif
 #ifndef MCS_PARK_HELIX_MAX
 #define MCS_PARK_HELIX_MAX 2048 // only particles younger than this many passes park
