@@ -56,10 +56,14 @@ struct KArgs {
 // a few cache lines -- cold particles most of all -- and a memory-side fp64 atomic takes ~12 ns per line: the first
 // pcut of a species ran at the atomic rate (21 ms instead of 6).  Each block adds to replica blockIdx % R; the host
 // folds the replicas into T before anything reads the tallies (mcs_sync, mcs_read_tallies, the consumers, ...).
+#ifndef MCS_TALLY_REPLICAS
 #define MCS_TALLY_REPLICAS 16
+#endif
 
 // particles waiting for their full Code Blocks, per wave (see the park logic of the transport kernel)
+#ifndef MCS_PARK_SLOTS
 #define MCS_PARK_SLOTS 16
+#endif
 #define MCS_PARK_WORDS 36
 #define MCS_PARK_WAVES 4096   // launches with more waves than this do not park
 

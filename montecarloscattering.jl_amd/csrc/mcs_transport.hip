@@ -49,6 +49,9 @@
 #define MCS_REFILL_MIN 12       // idle lanes a wave collects before it claims new particles: a refill stalls the wave for a memory latency,
                                 // and parked particles resume in batches of that size (final kernel: 6 -> 458 ms, 8 -> 451, 12 -> 442, 16 -> 444)
 #endif
+#ifndef MCS_MERGE_POLL_MASK
+#define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
+#endif
 #ifndef MCS_PARK_HELIX_MAX
 #define MCS_PARK_HELIX_MAX 2048 // only particles younger than this many passes park
 #endif
@@ -1520,7 +1523,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         base = __shfl(base, leader);
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
-          if (mrole != 0) mpoll_mask = 15u;
+          if (mrole != 0) mpoll_mask = MCS_MERGE_POLL_MASK;
 #ifdef MCS_PROF_TAIL
           if (lane == 0) S_ttgate[wv] = 1u;
 #endif
