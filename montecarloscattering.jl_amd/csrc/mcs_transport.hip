@@ -1201,9 +1201,11 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
   cand = cand < 0 ? 0 : (cand > ne - 2 ? ne - 2 : cand);
   double c_lo = S_x[cand], c_hi = S_x[cand + 1];
   double ux_c = S_ux[cand], gd_c = S_gd[cand], gsf_c = S_gsf[cand], bcos_c = S_bcos[cand], gef_c = S_gef[cand];
-  const bool adjacent = (fwd ? c_hi > p.x : c_lo <= p.x) && cand != p.i_grid;
-  const bool shock = p.x_old < 0 && p.x >= 0;
-  if (MCS_UNLIKELY(!adjacent && !shock)) {
+  // (selects and bitwise logic: && / ?: on comparisons compile to exec-mask regions at ~40 cycles each)
+  const double edge = fwd ? c_hi : c_lo;
+  const bool adjacent = (fwd ? (edge > p.x) : (edge <= p.x)) & (cand != p.i_grid);
+  const bool shock = (p.x_old < 0) & (p.x >= 0);
+  if (MCS_UNLIKELY(!adjacent & !shock)) {
     // one step can cross several of the thin zones near the shock: the search loop
     // (the zone's own edge and the neighbour's far edge are known to fail: two candidates skipped)
     cand = zone_search(p.x, fwd, p.i_grid, ne, 2);
@@ -1211,9 +1213,9 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
     c_lo = S_x[c]; c_hi = S_x[c + 1];
     ux_c = S_ux[c]; gd_c = S_gd[c]; gsf_c = S_gsf[c]; bcos_c = S_bcos[c]; gef_c = S_gef[c];
   }
-  const bool ok = !shock && cand >= 0 && cand > h.i_grid_feb && ux_c == p.z_ux && gd_c == p.gyro_denom;
+  const bool ok = !shock & (cand >= 0) & (cand > h.i_grid_feb) & (ux_c == p.z_ux) & (gd_c == p.gyro_denom);
   if (ok) {
-    if (p.downstream && p.x < 0) p.inj = true;
+    p.inj = p.inj | (p.downstream & (p.x < 0));
     p.i_grid_old = p.i_grid;
     p.i_grid = cand;
     push_record(p, p.ig3, (int)stack_height);     // the first push site of a pass: the height is the register mirror
