@@ -1201,6 +1201,9 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
   cand = cand < 0 ? 0 : (cand > ne - 2 ? ne - 2 : cand);
   double c_lo = S_x[cand], c_hi = S_x[cand + 1];
   double ux_c = S_ux[cand], gd_c = S_gd[cand], gsf_c = S_gsf[cand], bcos_c = S_bcos[cand], gef_c = S_gef[cand];
+  // all seven reads are in flight before the first is waited for (otherwise the compiler sinks some of them to
+  // their uses: three LDS round trips of ~130 cycles instead of one)
+  asm volatile("" : "+v"(c_lo), "+v"(c_hi), "+v"(ux_c), "+v"(gd_c), "+v"(gsf_c), "+v"(bcos_c), "+v"(gef_c));
   // (selects and bitwise logic: && / ?: on comparisons compile to exec-mask regions at ~40 cycles each)
   const double edge = fwd ? c_hi : c_lo;
   const bool adjacent = (fwd ? (edge > p.x) : (edge <= p.x)) & (cand != p.i_grid);
