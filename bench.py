@@ -23,7 +23,10 @@ Extra objects in the JSON line:
                the kernel's stream, summed over the launches of the timed region).
   cpu_baseline the CPU oracle (C++ restatement, glibc libm, OpenMP over particles on all
                host cores) on a bounded sample of the same workload -- a surrogate for
-               the Julia reference, which cannot run here.
+               the Julia reference, which cannot run here; `single_thread` inside it is
+               the same code on one core (the reference itself is serial), smaller sample.
+  load_balance (N > 1) the largest local population over the mean, per pcut: worst and
+               step-weighted mean over the timed iterations.
 """
 import argparse
 import json
@@ -38,7 +41,7 @@ FLOP_PER_STEP = 400.0          # weighted algorithmic fp
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 
 
-def cpu_baseline(mcs, n_sample, n_itrs=1):
+def cpu_baseline(mcs, n_sample, n_itrs=1, n_sample_1t=None):
     """Timed CPU leg (rank 0, N=1 only): the oracle is used here as the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
@@ -47,21 +50,31 @@ def cpu_baseline(mcs, n_sample, n_itrs=1):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))           # the GPU box gives one GPU a share of the host cores
-    cfg = mcs.inputs.Config(N_PTS_INJ=n_sample, N_PTS_PCUT=n_sample, N_PTS_PCUT_HI=n_sample)
-    prob = mcs.inputs.build_problem(cfg)
-    be = orc.OracleBackend(mcs.capi, "libm", nthreads=cores)
-    be.create(prob)
-    t0 = time.perf_counter()
-    res = mcs.driver.run(prob, be, None, n_itrs=n_itrs)
-    dt = time.perf_counter() - t0
-    steps = res.steps_helix + res.steps_retro
+
+    def timed(n, threads):
+        cfg = mcs.inputs.Config(N_PTS_INJ=n, N_PTS_PCUT=n, N_PTS_PCUT_HI=n)
+        prob = mcs.inputs.build_problem(cfg)
+        be = orc.OracleBackend(mcs.capi, "libm", nthreads=threads)
+        be.create(prob)
+        t0 = time.perf_counter()
+        res = mcs.driver.run(prob, be, None, n_itrs=n_itrs)
+        dt = time.perf_counter() - t0
+        be.destroy()
+        return res.steps_helix + res.steps_retro, dt
+
+    steps, dt = timed(n_sample, cores)
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": steps / dt, "unit": "particle-scatter steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} protons, all 45 pcuts, {n_itrs} iteration, {steps} steps in {dt:.1f} s; "
-                      f"C++ surrogate of the Julia reference (glibc libm, OpenMP dynamic over particles); cpu: {model}"}
+    out = {"value": steps / dt, "unit": "particle-scatter steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n_sample} protons, all 45 pcuts, {n_itrs} iteration, {steps} steps in {dt:.1f} s; "
+                     f"C++ surrogate of the Julia reference (glibc libm, OpenMP dynamic over particles); cpu: {model}"}
+    if n_sample_1t:
+        s1, d1 = timed(n_sample_1t, 1)
+        out["single_thread"] = {"value": s1 / d1, "unit": "particle-scatter steps/s", "cores": 1,
+                                "sample": f"{n_sample_1t} protons, all 45 pcuts, {s1} steps in {d1:.1f} s (the reference is serial)"}
+    return out
 
 
 def main():
@@ -71,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--cpu-sample", type=int, default=60000)
+    ap.add_argument("--cpu-sample-1t", type=int, default=3000, help="particles of the single-thread CPU leg (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -83,8 +97,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     # Rehearsal knobs (tests of the N > 1 code path on a one-GPU box): every rank on one device, gloo
     # instead of RCCL.  Never set by the driver.
@@ -147,15 +161,23 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    traffic = None
-    try:   # HBM bytes per K1 launch from the committed PMC passes (tools/profile_bench.sh)
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    # HBM bytes per K1 launch: NOT measured by this process -- the committed result of the separate
+    # `rocprofv3 --pmc` passes over this same command (tools/profile_bench.sh), labelled as such
+    traffic, traffic_src = None, None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"]
+            traffic_src = f"static: profiles/{name} (rocprofv3 --pmc passes of this command at the commit named there, not this run)"
+            break
+        except Exception:
+            pass
+    # this rank's own steps in the timed region (the kernel-level roofline is per GPU); rank 0 reports its own
+    local_steps = sum(n for (it, _, n) in res.local_steps if it > args.warmup)
+    timed = [s for s in res.stats if s.i_iter > args.warmup]
+    skew = [s.n_use_max * world / max(s.n_pts_use, 1) for s in timed]
     if rank == 0:
         value = steps_total / elapsed
-        local_steps = steps_total / world          # shards are balanced by construction
         ach = local_steps * FLOP_PER_STEP / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         out = {
             "metric": "particle-scatter steps/sec + wall-time per iter, 10^6 particles, 1->8 MI355X",
@@ -170,15 +192,20 @@ def main():
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"particle shards x{world}, all-gather(n_saved)/pcut, all-reduce(tallies)/iter"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "mcs_k_transport_plain (the specialisation of mcs_k_transport for this configuration)", "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                          "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "
                                  "HBM traffic is << 1 B/step (68 B in + 69 B out per particle per pcut)"},
         }
+        out["load_balance"] = {"max_over_mean_worst": max(skew), "max_over_mean_time_weighted":
+                               sum(k * s.kernel_ms for k, s in zip(skew, timed)) / max(sum(s.kernel_ms for s in timed), 1e-30),
+                               "gather_splits": sum(1 for s in timed if s.split == "gather"),
+                               "local_splits": sum(1 for s in timed if s.split == "local"),
+                               "note": "largest local population / mean, per pcut (1.0 = perfectly balanced)"}
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample, n_sample_1t=args.cpu_sample_1t)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

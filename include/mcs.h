@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCS_ABI_VERSION 1
+#define MCS_ABI_VERSION 2
 
 /* ---- physical constants (cgs).  The reference takes them from Unitful /
  * UnitfulGaussian / PhysicalConstants.CODATA2018 (src/MonteCarloScattering.jl:10-12,
@@ -56,6 +56,10 @@ extern "C" {
 #define MCS_SPIKE_AWAY   1000.0  /* all_flux.jl:4, particle_finish.jl:5 */
 #define MCS_HELIX_CAP    10000   /* particle_loop.jl:162 */
 #define MCS_RETRO_XN_PER 10.0    /* prob_return.jl:229 */
+/* The reference's retro_time loop is uncapped (prob_return.jl:257); a walk that never comes back to the
+ * PRP would hang the GPU.  After this many inner steps of ONE walk the particle ends with i_reason 3
+ * and MCS_IC_RETRO_CAP is bumped (identically in the oracle).  mcs_set_retro_cap overrides it (tests). */
+#define MCS_RETRO_CAP    10000000
 #define MCS_FLOOR        1.0e-99 /* particle_loop.jl:315-317, ion_init.jl:11-13 */
 
 /* i_reason codes (src/particle_loop.jl:138, src/particle_finish.jl:81-105) */
@@ -129,6 +133,7 @@ enum {
   MCS_IC_TCUT_OVERRUN,          /* tcut index past n_tcuts (reference would throw BoundsError) */
   MCS_IC_RNG_DRAWS,
   MCS_IC_ZONE_FAIL,              /* src/all_flux.jl:73-75 would throw */
+  MCS_IC_RETRO_CAP,              /* retro_time walks ended by MCS_RETRO_CAP (the reference would never return) */
   MCS_IC_COUNT
 };
 
@@ -225,9 +230,28 @@ int mcs_init_pop_binned(mcs_ctx* ctx, int64_t n_local, int64_t j_offset, int64_t
  * i_prt_offset: global index of local particle 0 minus 1 (multi-GPU shards;
  * the RNG key uses the global i_prt).  n_saved: particles that reached pcut. */
 int mcs_run_pcut(mcs_ctx* ctx, int i_pcut, int64_t i_prt_offset, int64_t* n_saved);
+/* The same over a strided shard: local particle k carries the global 0-based index
+ * i_prt_first + k * i_prt_stride (its RNG key uses that index + 1, as i_prt in
+ * src/particle_loop.jl:35-40).  mcs_run_pcut(c, i, off, ns) == mcs_run_pcut_strided(c, i, off, 1, ns). */
+int mcs_run_pcut_strided(mcs_ctx* ctx, int i_pcut, int64_t i_prt_first, int64_t i_prt_stride, int64_t* n_saved);
 /* K2: pcut_finalize/new_pcut (src/cuts.jl:34-124) on device: stable compaction
  * of l_save and i_mult-fold replication with weight/i_mult. Returns new size. */
 int mcs_new_pcut(mcs_ctx* ctx, int64_t i_mult, int64_t* n_new);
+/* Multi-GPU form of new_pcut.  The reference builds the next population from ALL saved particles
+ * (src/cuts.jl:34-98); with the population sharded over GPUs a local split leaves the late pcuts -- a
+ * handful of saved particles, each replicated 10^5 times -- on one or two ranks.  Instead:
+ *   mcs_saved_export  writes the saved particles of the last mcs_run_pcut*, compacted in index order, into
+ *     caller-owned DEVICE buffers (torch tensors, all-gathered by the caller over RCCL):
+ *     gidx[r] = global 0-based index of the r-th saved particle, f64[f * cap + r] = field f of it (the 8
+ *     doubles of mcs_soa, in that order), meta[r] = grid | tcut << 16 | downstream << 24 | inj << 25.
+ *     cap >= n_saved of that run.
+ *   mcs_split_import  makes the new local population from n_parents parents in device buffers of the same
+ *     layout, sorted by global index by the caller: local particle k is element o = first + k * stride of
+ *     the global split population  o -> parent[o / i_mult]  with weight / i_mult  (the index arithmetic of
+ *     src/cuts.jl:66-92 with a global o).  Global indices -- hence RNG keys -- are those of a one-GPU run. */
+int mcs_saved_export(mcs_ctx* ctx, int64_t cap, int64_t* dev_gidx, double* dev_f64, uint32_t* dev_meta);
+int mcs_split_import(mcs_ctx* ctx, int64_t n_parents, int64_t cap, const double* dev_f64, const uint32_t* dev_meta,
+                     int64_t i_mult, int64_t first, int64_t stride, int64_t n_local);
 
 /* Host-buffer form of K1, the literal drop-in for the loop at main_loops.jl:228-292:
  * upload `in`, run, download saved arrays + l_save. */
@@ -270,7 +294,12 @@ enum mcs_fn { MCS_FN_SIN = 0, MCS_FN_COS, MCS_FN_ASIN, MCS_FN_ACOS, MCS_FN_ATAN2
               MCS_FN_MOD2PI, MCS_FN_SQRT, MCS_FN_DIV, MCS_FN_HYPOT1, MCS_FN_UNIFORM };
 int mcs_eval_fn(mcs_ctx* ctx, int fn, int64_t n, const double* a, const double* b, double* out);
 /* per-particle end state of the last mcs_run_pcut (bit-parity tests): i_reason
- * (0 = saved), helix_count, retro step count, final ptot_pf and x. Any pointer may be NULL. */
+ * (0 = saved), helix_count, retro step count, final ptot_pf and x. Any pointer may be NULL.
+ * The kernel records them only after mcs_set_debug_finals(ctx, 1) (24 B of stores per particle
+ * and pcut that the product path does not need); otherwise mcs_final_download fails. */
+int mcs_set_debug_finals(mcs_ctx* ctx, int on);
+/* inner-step cap of one retro_time walk (0 = MCS_RETRO_CAP); tests lower it to reach the cap path */
+int mcs_set_retro_cap(mcs_ctx* ctx, int64_t cap);
 int mcs_final_download(mcs_ctx* ctx, int64_t n, int32_t* reason, int32_t* helix_count,
                        int32_t* retro_count, double* ptot_pf, double* x_PT_cm);
 /* kernel time [ms] of the last mcs_run_pcut, from HIP events on the context stream */

@@ -14,7 +14,7 @@ import numpy as np
 
 from .constants import PSD_MAX, NA_C
 
-MCS_ABI_VERSION = 1
+MCS_ABI_VERSION = 2
 
 c_double_p = ct.POINTER(ct.c_double)
 c_int64_p = ct.POINTER(ct.c_int64)
@@ -120,7 +120,7 @@ class Population:
 # int64 tally slots after the n_grid num_crossings entries (enum in mcs.h)
 IC = {name: i for i, name in enumerate([
     "STEPS_HELIX", "STEPS_RETRO", "HELIX_CAP", "PPERP_CLAMP", "PSP_CLAMP", "MOMBIN_CLAMP",
-    "REASON0", "REASON1", "REASON2", "REASON3", "REASON4", "TCUT_OVERRUN", "RNG_DRAWS", "ZONE_FAIL"])}
+    "REASON0", "REASON1", "REASON2", "REASON3", "REASON4", "TCUT_OVERRUN", "RNG_DRAWS", "ZONE_FAIL", "RETRO_CAP"])}
 IC_COUNT = len(IC)
 
 FN = {name: i for i, name in enumerate(
@@ -216,7 +216,12 @@ def load_library() -> ct.CDLL:
         "mcs_init_pop": (i32, [vp, i64, i64, i64, c_double_p, c_double_p, dbl, i32, i32, i32]),
         "mcs_init_pop_binned": (i32, [vp, i64, i64, i64, i32, c_double_p, c_double_p, c_int64_p, dbl, i32, i32, i32]),
         "mcs_run_pcut": (i32, [vp, i32, i64, c_int64_p]),
+        "mcs_run_pcut_strided": (i32, [vp, i32, i64, i64, c_int64_p]),
         "mcs_new_pcut": (i32, [vp, i64, c_int64_p]),
+        "mcs_saved_export": (i32, [vp, i64, vp, vp, vp]),
+        "mcs_split_import": (i32, [vp, i64, i64, vp, vp, i64, i64, i64, i64]),
+        "mcs_set_debug_finals": (i32, [vp, i32]),
+        "mcs_set_retro_cap": (i32, [vp, i64]),
         "mcs_run_pcut_host": (i32, [vp, i32, i64, i64, soa_p, soa_p, c_uint8_p, c_int64_p]),
         "mcs_read_tallies": (i32, [vp, c_double_p, c_int64_p]),
         "mcs_write_tallies": (i32, [vp, c_double_p, c_int64_p]),
@@ -243,4 +248,5 @@ EXPORTED_SYMBOLS = [
     "mcs_pop_size", "mcs_init_pop", "mcs_init_pop_binned", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
+    "mcs_run_pcut_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
 ]

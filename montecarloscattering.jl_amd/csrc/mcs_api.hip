@@ -18,9 +18,13 @@ extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st);
-hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
-                               unsigned int* block_counts, unsigned long long* block_offsets,
-                               unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st);
+hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                              unsigned long long* total_dev, long long* src, hipStream_t st);
+hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st);
+hipError_t mcs_launch_saved_export(DevPop sv, const long long* src, long long n_saved, long long cap, long long first,
+                                   long long stride, long long* gidx, double* f64, uint32_t* meta, hipStream_t st);
+hipError_t mcs_launch_split_import(DevPop out, const double* f64, const uint32_t* meta, long long cap, long long i_mult,
+                                   long long first, long long stride, long long n_local, hipStream_t st);
 hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
                                long long n_total, unsigned long long key, double m, double u, double x_start,
                                int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
@@ -71,6 +75,10 @@ struct mcs_ctx {
   uint8_t* d_lsave = nullptr; long long lsave_cap = 0;
   long long n = 0;             // current population size
   long long n_saved_last = 0;
+  long long n_run_last = 0;    // population size of the last mcs_run_pcut (the saved arrays and src[] refer to it)
+  long long idx_first = 0, idx_stride = 1;   // global index of local particle k in that run: idx_first + k * idx_stride
+  bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
+  int retro_cap = MCS_RETRO_CAP;
   // finals
   int32_t *f_reason = nullptr, *f_helix = nullptr, *f_retro = nullptr; double *f_ptot = nullptr, *f_x = nullptr;
   long long f_cap = 0;
@@ -145,7 +153,7 @@ int ensure_capacity(mcs_ctx* c, long long n) {
     HIPCHK(hipMalloc((void**)&c->d_lsave, (size_t)cap));
     c->lsave_cap = cap;
   }
-  if (n > c->f_cap) {
+  if (c->debug_finals && n > c->f_cap) {
     long long cap = n + n / 8 + 1024;
     if (c->f_reason) { (void)hipFree(c->f_reason); (void)hipFree(c->f_helix); (void)hipFree(c->f_retro); (void)hipFree(c->f_ptot); (void)hipFree(c->f_x); }
     HIPCHK(hipMalloc((void**)&c->f_reason, (size_t)cap * 4)); HIPCHK(hipMalloc((void**)&c->f_helix, (size_t)cap * 4));
@@ -430,6 +438,13 @@ int mcs_pop_upload(mcs_ctx* c, int64_t n, const mcs_soa* host) {
     if (!(host->ptot_pf[k] > 0)) return fail("mcs_pop_upload: ptot_pf must be > 0 (zero-momentum particle: reference quirk G6)");
     if (host->grid[k] < 0 || host->grid[k] > c->P.n_grid) return fail("mcs_pop_upload: grid index out of 0..n_grid");
     if (host->tcut[k] < 1 || host->tcut[k] > 255) return fail("mcs_pop_upload: tcut out of range");
+    // a non-finite position or momentum never satisfies an exit test (NaN compares false): the helix loop would run
+    // into its cap and the retro walk into MCS_RETRO_CAP -- refuse it here (the reference would loop forever)
+    if (!std::isfinite(host->ptot_pf[k]) || !std::isfinite(host->pb_pf[k]) || !std::isfinite(host->x_PT_cm[k]) ||
+        !std::isfinite(host->prp_x_cm[k]) || !std::isfinite(host->acctime_sec[k]) || !std::isfinite(host->phi_rad[k]) ||
+        !std::isfinite(host->weight[k]))
+      return fail("mcs_pop_upload: weight, ptot_pf, pb_pf, x_PT_cm, prp_x_cm, acctime_sec and phi_rad must be finite");
+    if (!(host->xn_per[k] > 0) || !std::isfinite(host->xn_per[k])) return fail("mcs_pop_upload: xn_per must be finite and > 0");
   }
   c->n = 0;
   if (ensure_capacity(c, n)) return 1;
@@ -456,7 +471,10 @@ int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const
   HIPCHK(hipSetDevice(c->device));
   if (!c->have_grid) return fail("mcs_init_pop: call mcs_set_grid first");
   if (n < 0 || i_grid_start < 0 || i_grid_start > c->P.n_grid) return fail("mcs_init_pop: bad arguments");
-  for (int64_t k = 0; k < n; ++k) if (!(ptot_pf_in[k] > 0)) return fail("mcs_init_pop: ptot_pf must be > 0 (reference quirk G6)");
+  if (!std::isfinite(x_start_cm)) return fail("mcs_init_pop: x_start_cm must be finite");
+  for (int64_t k = 0; k < n; ++k)
+    if (!(ptot_pf_in[k] > 0) || !std::isfinite(ptot_pf_in[k]) || !std::isfinite(weight_in[k]))
+      return fail("mcs_init_pop: ptot_pf must be finite and > 0 (reference quirk G6), weight finite");
   c->n = 0;
   if (ensure_capacity(c, n)) return 1;
   if (ensure_stage(c, 2 * n + 2)) return 1;
@@ -484,8 +502,10 @@ int mcs_init_pop_binned(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total
     return fail("mcs_init_pop_binned: bin_start must run from 0 to n_total and the shard must lie inside");
   for (int b = 0; b < n_bins; ++b) {
     if (bin_start[b + 1] < bin_start[b]) return fail("mcs_init_pop_binned: bin_start must be non-decreasing");
-    if (bin_start[b + 1] > bin_start[b] && !(bin_ptot_pf[b] > 0)) return fail("mcs_init_pop_binned: ptot_pf must be > 0 (reference quirk G6)");
+    if (bin_start[b + 1] > bin_start[b] && (!(bin_ptot_pf[b] > 0) || !std::isfinite(bin_ptot_pf[b]) || !std::isfinite(bin_weight[b])))
+      return fail("mcs_init_pop_binned: ptot_pf must be finite and > 0 (reference quirk G6), weight finite");
   }
+  if (!std::isfinite(x_start_cm)) return fail("mcs_init_pop_binned: x_start_cm must be finite");
   c->n = 0;
   if (ensure_capacity(c, n)) return 1;
   const size_t nd = (size_t)3 * n_bins + 1;      // ptot | weight | start (int64 in a double slot)
@@ -512,8 +532,20 @@ int mcs_set_launch(mcs_ctx* c, int blocks, int threads) {
   return 0;
 }
 
+int mcs_set_debug_finals(mcs_ctx* c, int on) { c->debug_finals = on != 0; return 0; }
+int mcs_set_retro_cap(mcs_ctx* c, int64_t cap) {
+  if (cap < 0 || cap > 2000000000LL) return fail("mcs_set_retro_cap: cap out of range");
+  c->retro_cap = cap > 0 ? (int)cap : MCS_RETRO_CAP;
+  return 0;
+}
+
 int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved) {
+  return mcs_run_pcut_strided(c, i_pcut, i_prt_offset, 1, n_saved);
+}
+
+int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i_prt_stride, int64_t* n_saved) {
   HIPCHK(hipSetDevice(c->device));
+  if (i_prt_offset < 0 || i_prt_stride < 1) return fail("mcs_run_pcut: i_prt_first must be >= 0 and i_prt_stride >= 1");
   if (!c->have_grid || !c->have_cuts) return fail("mcs_run_pcut: grid/cuts not set");
   if (i_pcut < 1 || i_pcut > c->tb.n_pcuts) return fail("mcs_run_pcut: i_pcut out of range");
   const long long n = c->n;
@@ -525,7 +557,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
     for (auto p : sv) HIPCHK(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->sav.d.meta, 0, (size_t)n * sizeof(uint32_t), c->stream));
   }
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
 
   KArgs& a = c->h_args;
   std::memset(&a, 0, sizeof(a));
@@ -536,7 +568,8 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   a.pcut = c->h_pcuts[i_pcut - 1];
   a.pcut_prev = i_pcut > 1 ? c->h_pcuts[i_pcut - 2] : 0.0;
   a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
-  a.n = n; a.i_prt_offset = i_prt_offset;
+  a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride;
+  a.retro_cap = c->retro_cap;
   // iseed_mod - i_prt, src/particle_loop.jl:35-40
   a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
                                      (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
@@ -545,7 +578,7 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   a.tail_merge = c->tail_merge ? 1 : 0;
   a.park = c->park ? c->d_park : nullptr;
   a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
-  a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x;
+  if (c->debug_finals) { a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x; }
 
   const int threads = c->threads;
   int blocks = c->blocks;
@@ -564,35 +597,66 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
   if (n > 0) { HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream)); c->rep_dirty = true; }
   HIPCHK(hipEventRecord(c->ev1, c->stream));
-  unsigned long long ns = 0;
-  HIPCHK(hipMemcpyAsync(&ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+  // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
+  // independent count of the l_save flags next to the kernel's own n_saved counter, read back together
+  HIPCHK(mcs_launch_compact(c->d_lsave, n, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src, c->stream));
+  unsigned long long ns[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_ms = ms;
-  c->n_saved_last = (long long)ns;
-  if (n_saved) *n_saved = (int64_t)ns;
+  c->n_saved_last = (long long)ns[0];
+  c->n_run_last = n; c->idx_first = i_prt_offset; c->idx_stride = i_prt_stride;
+  // every entry point that hands out l_save or the saved arrays goes through here (a spilling build of the kernel
+  // once miscompiled the l_save byte store, see csrc/Makefile)
+  if (ns[0] != ns[1]) return fail("mcs_run_pcut: the kernel's n_saved counter and the count of l_save flags differ");
+  if (n_saved) *n_saved = (int64_t)ns[0];
   return 0;
 }
 
 int mcs_new_pcut(mcs_ctx* c, int64_t i_mult, int64_t* n_new_out) {
   HIPCHK(hipSetDevice(c->device));
   if (i_mult < 1) return fail("mcs_new_pcut: i_mult < 1");
-  const long long n = c->n, n_saved = c->n_saved_last;
+  if (c->n != c->n_run_last) return fail("mcs_new_pcut: no mcs_run_pcut since the population changed");
+  const long long n_saved = c->n_saved_last;
   const long long n_new = n_saved * i_mult;
-  // the split writes into the spare buffer, then the buffers rotate
+  // the split (src[] was computed behind the transport kernel) writes into the spare buffer, then the buffers
+  // rotate; nothing is read back: the new size is known on the host
   if (pop_alloc(c, c->spare, n_new + n_new / 8 + 1024)) return 1;
-  if (ensure_capacity(c, n)) return 1;
-  HIPCHK(mcs_launch_new_pcut(c->d_lsave, n, c->sav.d, c->spare.d, i_mult, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src,
-                             n_saved, c->stream));
-  unsigned long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, c->d_counters + 2, sizeof(total), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (n > 0 && (long long)total != n_saved) return fail("mcs_new_pcut: scan total != n_saved");
+  HIPCHK(mcs_launch_split(c->sav.d, c->spare.d, c->d_src, n_new, i_mult, c->stream));
   PopBuf t = c->cur; c->cur = c->spare; c->spare = t;
-  c->n = n_new;
+  c->n = n_new; c->n_run_last = -1;
   if (ensure_capacity(c, n_new)) return 1;
   if (n_new_out) *n_new_out = n_new;
+  return 0;
+}
+
+int mcs_saved_export(mcs_ctx* c, int64_t cap, int64_t* dev_gidx, double* dev_f64, uint32_t* dev_meta) {
+  HIPCHK(hipSetDevice(c->device));
+  if (c->n != c->n_run_last) return fail("mcs_saved_export: no mcs_run_pcut since the population changed");
+  if (cap < c->n_saved_last) return fail("mcs_saved_export: cap < n_saved");
+  if (c->n_saved_last > 0 && (!dev_gidx || !dev_f64 || !dev_meta)) return fail("mcs_saved_export: null buffer");
+  HIPCHK(mcs_launch_saved_export(c->sav.d, c->d_src, c->n_saved_last, cap, c->idx_first, c->idx_stride, (long long*)dev_gidx,
+                                 dev_f64, dev_meta, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));      // the caller's library (RCCL on another stream) may read the buffers now
+  return 0;
+}
+
+int mcs_split_import(mcs_ctx* c, int64_t n_parents, int64_t cap, const double* dev_f64, const uint32_t* dev_meta, int64_t i_mult,
+                     int64_t first, int64_t stride, int64_t n_local) {
+  HIPCHK(hipSetDevice(c->device));
+  if (i_mult < 1 || stride < 1 || first < 0 || n_local < 0 || n_parents < 0 || cap < n_parents)
+    return fail("mcs_split_import: bad arguments");
+  if (n_local > 0 && (first + (n_local - 1) * stride) / i_mult >= n_parents)
+    return fail("mcs_split_import: the local slice reaches past n_parents * i_mult");
+  if (n_local > 0 && (!dev_f64 || !dev_meta)) return fail("mcs_split_import: null buffer");
+  if (pop_alloc(c, c->spare, n_local + n_local / 8 + 1024)) return 1;
+  HIPCHK(mcs_launch_split_import(c->spare.d, dev_f64, dev_meta, cap, i_mult, first, stride, n_local, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));      // the caller may free or reuse its buffers
+  PopBuf t = c->cur; c->cur = c->spare; c->spare = t;
+  c->n = n_local; c->n_run_last = -1;
+  if (ensure_capacity(c, n_local)) return 1;
   return 0;
 }
 
@@ -635,6 +699,7 @@ int mcs_eval_fn(mcs_ctx* c, int fn, int64_t n, const double* a, const double* b,
 int mcs_final_download(mcs_ctx* c, int64_t n, int32_t* reason, int32_t* helix_count, int32_t* retro_count, double* ptot_pf,
                        double* x_PT_cm) {
   HIPCHK(hipSetDevice(c->device));
+  if (!c->debug_finals) return fail("mcs_final_download: end states are recorded only after mcs_set_debug_finals(ctx, 1)");
   if (n > c->f_cap) return fail("mcs_final_download: n too large");
   if (reason) HIPCHK(hipMemcpyAsync(reason, c->f_reason, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   if (helix_count) HIPCHK(hipMemcpyAsync(helix_count, c->f_helix, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

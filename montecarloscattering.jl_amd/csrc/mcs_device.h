@@ -41,6 +41,7 @@ struct KArgs {
   int i_iter, i_ion, i_pcut;
   long long n;               // local population size
   long long i_prt_offset;    // global i_prt of local particle 0, minus 1
+  long long i_prt_stride;    // global i_prt of local particle k = i_prt_offset + 1 + k * i_prt_stride (1: a contiguous shard)
   unsigned long long seed_base;   // iseed_mod - i_prt   (src/particle_loop.jl:35-40)
   unsigned long long* work_counter;   // next unclaimed particle
   unsigned long long* n_saved;
@@ -49,6 +50,7 @@ struct KArgs {
   double* tally_rep;         // MCS_TALLY_REPLICAS private copies of T[0 .. rep_n) for the per-event tallies (the LDS-staged
   long long rep_n;           // sums are flushed into T itself); null / 0: tally into T
   double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
+  int retro_cap;             // inner steps after which one retro_time walk is ended (MCS_RETRO_CAP; tests lower it)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
 };
 

@@ -131,6 +131,44 @@ mcs_k_split(DevPop sv, DevPop out, const long long* __restrict__ src, long long 
   out.meta[o] = sv.meta[j];
 }
 
+// K2e (multi-GPU new_pcut): the saved particles, compacted in index order, into caller-owned buffers that the host
+// all-gathers: field f of the r-th saved particle at f64[f * cap + r]; its global index first + src[r] * stride.
+extern "C" __global__ void __launch_bounds__(256)
+mcs_k_saved_export(DevPop sv, const long long* __restrict__ src, long long n_saved, long long cap, long long first,
+                   long long stride, long long* __restrict__ gidx, double* __restrict__ f64, uint32_t* __restrict__ meta) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_saved) return;
+  const long long j = src[r];
+  gidx[r] = first + j * stride;
+  f64[r] = sv.weight[j];
+  f64[cap + r] = sv.ptot_pf[j];
+  f64[2 * cap + r] = sv.pb_pf[j];
+  f64[3 * cap + r] = sv.x_PT_cm[j];
+  f64[4 * cap + r] = sv.xn_per[j];
+  f64[5 * cap + r] = sv.prp_x_cm[j];
+  f64[6 * cap + r] = sv.acctime_sec[j];
+  f64[7 * cap + r] = sv.phi_rad[j];
+  meta[r] = sv.meta[j];
+}
+// K2f: local particle k = element o = first + k * stride of the global split population o -> parent[o / i_mult]
+// (src/cuts.jl:66-92 with a global o); parents in the layout of mcs_k_saved_export, sorted by global index.
+extern "C" __global__ void __launch_bounds__(256)
+mcs_k_split_import(DevPop out, const double* __restrict__ f64, const uint32_t* __restrict__ meta, long long cap,
+                   long long i_mult, long long first, long long stride, long long n_local) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_local) return;
+  const long long j = (first + k * stride) / i_mult;
+  out.weight[k] = f64[j] / (double)i_mult;
+  out.ptot_pf[k] = f64[cap + j];
+  out.pb_pf[k] = f64[2 * cap + j];
+  out.x_PT_cm[k] = f64[3 * cap + j];
+  out.xn_per[k] = f64[4 * cap + j];
+  out.prp_x_cm[k] = f64[5 * cap + j];
+  out.acctime_sec[k] = f64[6 * cap + j];
+  out.phi_rad[k] = f64[7 * cap + j];
+  out.meta[k] = meta[j];
+}
+
 // K3: initial population.
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_init_pop(DevPop out, const double* __restrict__ ptot_in, const double* __restrict__ weight_in, long long n,
@@ -216,17 +254,35 @@ extern "C" __global__ void mcs_k_eval_fn(int fn, long long n, const double* a, c
 // host launchers (called from mcs_api.hip)
 extern "C" {
 
-hipError_t mcs_launch_new_pcut(const uint8_t* l_save, long long n, DevPop sv, DevPop out, long long i_mult,
-                               unsigned int* block_counts, unsigned long long* block_offsets,
-                               unsigned long long* total_dev, long long* src, long long n_saved, hipStream_t st) {
+// the compaction half of new_pcut: src[r] = local index of the r-th saved particle, *total_dev = their number.
+// Queued right behind the transport kernel by mcs_run_pcut, so that ONE read-back brings both the kernel's own
+// n_saved counter and this independent count of l_save (they must agree) and nothing has to be waited for later.
+hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                              unsigned long long* total_dev, long long* src, hipStream_t st) {
   const long long nb = (n + 1023) / 1024;
-  if (nb == 0) return hipSuccess;
+  if (nb == 0) return hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), st);
   hipLaunchKernelGGL(mcs_k_count_saved, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_counts);
   hipLaunchKernelGGL(mcs_k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets, total_dev);
   hipLaunchKernelGGL(mcs_k_compact_index, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_offsets, src);
-  const long long n_new = n_saved * i_mult;
+  return hipGetLastError();
+}
+hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st) {
   if (n_new > 0)
     hipLaunchKernelGGL(mcs_k_split, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, st, sv, out, src, n_new, i_mult);
+  return hipGetLastError();
+}
+hipError_t mcs_launch_saved_export(DevPop sv, const long long* src, long long n_saved, long long cap, long long first,
+                                   long long stride, long long* gidx, double* f64, uint32_t* meta, hipStream_t st) {
+  if (n_saved > 0)
+    hipLaunchKernelGGL(mcs_k_saved_export, dim3((unsigned)((n_saved + 255) / 256)), dim3(256), 0, st, sv, src, n_saved, cap,
+                       first, stride, gidx, f64, meta);
+  return hipGetLastError();
+}
+hipError_t mcs_launch_split_import(DevPop out, const double* f64, const uint32_t* meta, long long cap, long long i_mult,
+                                   long long first, long long stride, long long n_local, hipStream_t st) {
+  if (n_local > 0)
+    hipLaunchKernelGGL(mcs_k_split_import, dim3((unsigned)((n_local + 255) / 256)), dim3(256), 0, st, out, f64, meta, cap,
+                       i_mult, first, stride, n_local);
   return hipGetLastError();
 }
 

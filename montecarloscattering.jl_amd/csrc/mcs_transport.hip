@@ -550,6 +550,7 @@ struct Retro {
   int tcut, n_retro;
   uint32_t rng_n;
   bool lose_pt;
+  bool capped;       // the walk was ended by MCS_RETRO_CAP (not in the reference, whose loop is uncapped)
 };
 
 // src/prob_return.jl:217-344 (with D1: the scattered pitch is kept)
@@ -570,6 +571,9 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
   const double B_CMB_loc = P.B_CMBz * gef;
   double B2_tot = B * B + B_CMB_loc * B_CMB_loc;
   r.lose_pt = false;
+  r.capped = false;
+  const int n_retro_0 = r.n_retro;
+  const int retro_cap = a->retro_cap;
   double x_PT = prp;
   r.phi = rng.rand() * TWOPI_;
   const int n_tcuts = a->tb.n_tcuts;
@@ -620,6 +624,7 @@ __device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double w
       r.gam = mcsm::hypot1(r.ptot / mc);
     }
     if (x_PT < prp) break;
+    if (r.n_retro - n_retro_0 >= retro_cap) { r.capped = true; cnt(a, MCS_IC_RETRO_CAP); break; }   // see MCS_RETRO_CAP (include/mcs.h)
   }
   r.rng_n = rng.n;
   return r;
@@ -740,7 +745,7 @@ __device__ __forceinline__ void refresh_time(CK* a, const Hot& h, Pt& p) {
 
 // src/prob_return.jl:36-173, entered only when it has something to do (the caller has
 // already set i_return = 2 and filtered the no-op cases).
-__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt) {
+__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt, bool& capped) {
   const auto& P = a->P;
   const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
   if (p.x < x_grid_stop) {
@@ -764,13 +769,13 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
       Retro r;
       r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
       r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = tcut_next_of(a, h, p.tcut); r.tcut = p.tcut;
-      r.n_retro = p.n_retro; r.rng_n = rng.n; r.lose_pt = false;
+      r.n_retro = p.n_retro; r.rng_n = rng.n; r.lose_pt = false; r.capped = false;
       r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut = r.tcut;
-      p.n_retro = r.n_retro; rng.n = r.rng_n; lose_pt = r.lose_pt;
+      p.n_retro = r.n_retro; rng.n = r.rng_n; lose_pt = r.lose_pt; capped = r.capped;
       p.flags |= F_RS | F_RM;          // radiative losses inside the walk change ptot_pf / gam_pf
-      if (lose_pt) i_return = 0;
+      if (lose_pt | capped) i_return = 0;
       p.x = p.prp;
     }
   } else {
@@ -820,7 +825,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.ig3 = p.i_grid;
   load_zone_props(p); load_zone_edges(p);
   p.helix = 0; p.n_retro = 0;
-  const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k + 1);
+  const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k * a->i_prt_stride + 1);
   rng.init(key);
 
   p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);
@@ -1038,16 +1043,16 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
     const double L_diff = h.eta / 3 * v_fac;
     if (p.x > 6.91 * L_diff) { i_return = 0; do_prob_ret = false; TTG_COUNT(59); }
   }
-  bool lose_pt = false;
+  bool lose_pt = false, capped = false;
   TTG_MARK(43);
-  if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt);
+  if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt, capped);
   TTG_MARK(44);
   if (i_return == 0) {
     double vel = p.ptot_pf / h.m;
     if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
     sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
     sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
-    return lose_pt ? 4 : 1;
+    return capped ? 3 : (lose_pt ? 4 : 1);
   }
   // the particle goes on: what the next pass has to know
   int f = p.flags | F_CHECK;

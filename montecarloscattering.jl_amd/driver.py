@@ -13,6 +13,18 @@ of GPUs, the per-pcut collective is an all-gather of `n_saved` (8 B per rank)
 and the per-species collective is ONE sum-all-reduce of the flat tally buffer.
 Baseline fills (1e-99 floors, analytic fast-push fluxes) live on rank 0 only so
 that the sum is the single-GPU result.
+
+`new_pcut` across ranks (src/cuts.jl:34-98 rebuilds the population from ALL saved
+particles): while many particles are saved and every rank holds its share of them
+(max/mean <= 1.1), each rank splits its own -- contiguous global index ranges, no
+data moves.  In the late pcuts a handful of particles is saved and replicated 10^5
+times; a local split would put that whole population on the one or two ranks that
+happened to hold the parents.  Then (n_saved <= `gather_max`, or the counts are
+skewed) the compacted saved particles are all-gathered (68 B each), sorted by global
+index, and rank r takes the elements r, r+W, r+2W, ... of the global split
+population: every rank gets the same number of particles (+-1) and the same mix of
+parents.  Global indices -- hence RNG keys and per-particle results -- are those of a
+one-GPU run in both cases.
 """
 from __future__ import annotations
 
@@ -34,6 +46,8 @@ class PcutStat:
     n_pts_use: int          # global
     n_saved: int            # global
     i_mult: int
+    n_use_max: int          # largest local population of this pcut over the ranks (load balance: max/mean)
+    split: str              # how the NEXT population was built: "local" | "gather" | "-" (last pcut)
     kernel_ms: float        # local kernel time (HIP events), nan for CPU backends
     wall_ms: float
 
@@ -46,6 +60,7 @@ class RunResult:
     stats: List[PcutStat]
     steps_helix: int
     steps_retro: int
+    local_steps: list = dataclasses.field(default_factory=list)   # [(i_iter, i_ion, helix + retro steps made by THIS rank's kernels)]
 
 
 class Comm:
@@ -60,16 +75,31 @@ class Comm:
             self.dist = dist
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def all_gather_int(self, v: int) -> List[int]:
+    def all_gather_ints(self, vals) -> List[List[int]]:
+        """A few int64 per rank -> [rank][j] (one collective, one device-to-host copy)."""
+        vals = [int(v) for v in vals]
         if not self.enabled:
-            return [int(v)]
+            return [vals]
         import torch
         # NCCL/RCCL needs device tensors; gloo gathers on the host
         dev = self.device if self.dist.get_backend() == "nccl" else None
-        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
-        out = [torch.zeros_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        return [int(x) for x in torch.cat(out).tolist()]      # one device-to-host copy, not one per rank
+        t = torch.tensor(vals, dtype=torch.int64, device=dev)
+        out = torch.zeros(self.world * len(vals), dtype=torch.int64, device=dev)     # flat: gloo takes no other shape
+        self.dist.all_gather_into_tensor(out, t)
+        return out.view(self.world, len(vals)).tolist()
+
+    def all_gather_int(self, v: int) -> List[int]:
+        return [r[0] for r in self.all_gather_ints([v])]
+
+    def all_gather_cols(self, t, counts):
+        """t: [..., cap] on every rank, rank r's first counts[r] columns valid -> [..., sum(counts)], rank-major."""
+        import torch
+        if not self.enabled or self.world == 1:
+            return t[..., :counts[0]].contiguous()
+        flat = torch.zeros(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(flat, t.contiguous().view(-1))
+        out = flat.view((self.world,) + tuple(t.shape))
+        return torch.cat([out[r][..., :counts[r]] for r in range(self.world)], dim=-1).contiguous()
 
     def all_reduce_sum_(self, tensor):
         if self.enabled:
@@ -86,12 +116,13 @@ def shard_range(n: int, rank: int, world: int):
 
 def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[int] = None,
         max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
-        verbose: bool = False) -> RunResult:
+        verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
-    run_pcut/new_pcut/pop_size/read_tallies/write_tallies/last_kernel_ms
-    (HipBackend in hip_backend.py; tests inject the CPU oracle's).
+    run_pcut/new_pcut/export_saved/import_split/pop_size/read_tallies/write_tallies/
+    last_kernel_ms (HipBackend in hip_backend.py; tests inject the CPU oracle's).
+    gather_max / skew_max: see the module docstring (multi-rank new_pcut).
     """
     import torch
 
@@ -111,6 +142,10 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     # (CPU test backends) the same steps go through read_tallies/write_tallies.
     dev_t = backend.tally_tensors() if (multi and hasattr(backend, "tally_tensors")) else None
     G_pool = None       # merged energy_transfer_pool of the previous species
+    local_steps = []    # (i_iter, i_ion, steps this rank's kernels made for that species)
+    from .capi import IC as _IC
+    i_h, i_r = P.n_grid + _IC["STEPS_HELIX"], P.n_grid + _IC["STEPS_RETRO"]
+    steps_seen = 0      # the step counters are never reset: this rank's running total
 
     def tview(t, name):
         o = L.offsets[name]
@@ -152,13 +187,16 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             n_total = inj.n_pts_use
             lo, hi = shard_range(n_total, comm.rank, comm.world)
             backend.init_pop(inj, lo, hi - lo, n_total)
-            offset = lo
+            first, stride = lo, 1       # global index of local particle k: first + k * stride
+            n_local = hi - lo
             p_pcut_hi = inputs.pcut_hi(cfg.EN_PCUT_HI, sp.mass)
             n_use_global = n_total
             for i_pcut in range(1, n_pcuts + 1):
                 t0 = time.perf_counter()
-                n_saved_local = backend.run_pcut(i_pcut, offset)
-                counts = comm.all_gather_int(n_saved_local)
+                n_saved_local = backend.run_pcut(i_pcut, first, stride)
+                gathered = comm.all_gather_ints([n_saved_local, n_local])
+                counts = [g[0] for g in gathered]
+                n_use_max = max(g[1] for g in gathered)
                 n_saved = sum(counts)
                 wall = (time.perf_counter() - t0) * 1e3
                 # pcut_finalize (src/cuts.jl:100-124)
@@ -166,37 +204,62 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 if n_saved > 0:
                     n_target = cfg.N_PTS_PCUT if prob.pcuts[i_pcut - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI
                     i_mult = max(n_target // n_saved, 1)         # new_pcut, src/cuts.jl:42
-                stats.append(PcutStat(i_iter, i_ion, i_pcut, n_use_global, n_saved, i_mult,
-                                      backend.last_kernel_ms(), wall))
+                last = n_saved == 0 or i_pcut == n_pcuts
+                local_ok = stride == 1 and (not multi or (n_saved > gather_max and
+                                                          max(counts) * comm.world <= skew_max * n_saved))
+                st = PcutStat(i_iter, i_ion, i_pcut, n_use_global, n_saved, i_mult, n_use_max,
+                              "-" if last else ("local" if local_ok else "gather"), backend.last_kernel_ms(), wall)
+                stats.append(st)
                 if verbose and is_root:
-                    print(f"[iter {i_iter} ion {i_ion} pcut {i_pcut:2d}] n_use={n_use_global} n_saved={n_saved} "
-                          f"i_mult={i_mult} kernel={backend.last_kernel_ms():.2f} ms wall={wall:.1f} ms", flush=True)
+                    print(f"[iter {i_iter} ion {i_ion} pcut {i_pcut:2d}] n_use={n_use_global} (max local {n_use_max}) "
+                          f"n_saved={n_saved} i_mult={i_mult} split={st.split} kernel={backend.last_kernel_ms():.2f} ms "
+                          f"wall={wall:.1f} ms", flush=True)
                 if n_saved == 0:
                     break
-                backend.new_pcut(i_mult)
-                offset = sum(counts[:comm.rank]) * i_mult
                 n_use_global = n_saved * i_mult
+                if local_ok:
+                    # every rank splits its own saved particles: contiguous global ranges, rank-major = global order
+                    backend.new_pcut(i_mult)
+                    first, stride = sum(counts[:comm.rank]) * i_mult, 1
+                    n_local = counts[comm.rank] * i_mult
+                else:
+                    # all ranks see all parents (sorted by global index); rank r builds elements r, r+W, ... of the split
+                    gidx, f64, meta = backend.export_saved(max(max(counts), 1))
+                    gidx = comm.all_gather_cols(gidx, counts)
+                    f64 = comm.all_gather_cols(f64, counts)
+                    meta = comm.all_gather_cols(meta, counts)
+                    order = torch.argsort(gidx, stable=True)
+                    f64 = f64.index_select(1, order).contiguous()
+                    meta = meta.index_select(0, order).contiguous()
+                    first, stride = comm.rank, comm.world
+                    n_local = (n_use_global - comm.rank + comm.world - 1) // comm.world
+                    backend.import_split(f64, meta, n_saved, i_mult, first, stride, n_local)
 
             # species end: merge the partial tallies of all ranks (C1)
             if multi and dev_t is not None:
                 backend.sync()          # the bound tensors are complete after mcs_sync (it folds the tally replicas in)
                 tf, ti = dev_t
+                local_steps.append((i_iter, i_ion, int(ti[i_h].item() + ti[i_r].item()) - steps_seen))
                 if not is_root:   # every rank carried a full copy of the received-energy pool
                     tview(tf, "energy_recv_pool").zero_()
                 comm.all_reduce_sum_(tf)
                 comm.all_reduce_sum_(ti)
                 G_pool = tview(tf, "energy_transfer_pool").clone()
                 G_f, G_i = tf.cpu().numpy(), ti.cpu().numpy()
+                steps_seen = int(G_i[i_h] + G_i[i_r]) if is_root else 0     # rank 0 carries the merged totals on
                 if not is_root:
                     tf.zero_(); ti.zero_()
             else:
                 f, i = backend.read_tallies()
+                local_steps.append((i_iter, i_ion, int(i[i_h] + i[i_r]) - steps_seen))
+                steps_seen = int(i[i_h] + i[i_r])
                 if multi:
                     if not is_root:
                         L.view(f, "energy_recv_pool")[...] = 0.0
                     tf, ti = torch.from_numpy(f), torch.from_numpy(i)
                     comm.all_reduce_sum_(tf); comm.all_reduce_sum_(ti)
                     G_f, G_i = f.copy(), i.copy()
+                    steps_seen = int(G_i[i_h] + G_i[i_r]) if is_root else 0
                     G_pool = L.view(G_f, "energy_transfer_pool").copy()
                     if is_root:
                         backend.write_tallies(G_f, G_i)
@@ -211,4 +274,4 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     ng = P.n_grid
     from .capi import IC
     return RunResult(G_f, G_i, per_species, stats,
-                     int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]))
+                     int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]), local_steps)

@@ -24,15 +24,19 @@ def _dp(a: np.ndarray):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, device: int = 0, stream: int = 0, torch_tallies: bool = False):
-        """torch_tallies: keep the flat tally buffers in torch CUDA tensors on torch's current
-        stream, so that torch.distributed can all-reduce them in place (multi-GPU driver)."""
+    def __init__(self, device: int = 0, stream: int = 0, torch_tallies: bool = False, debug_finals: bool = False):
+        """torch_tallies: keep the flat tally buffers in torch CUDA tensors, so that torch.distributed can
+        all-reduce them in place (multi-GPU driver).  The context then works on torch's CURRENT stream
+        (passed to mcs_create), so torch ops and library kernels are ordered by that stream; with
+        stream=0 and torch_tallies=False the context creates its own blocking stream.
+        debug_finals: record per-particle end states for finals() (tests; 24 B of stores per particle)."""
         self.lib = capi.load_library()          # raises MissingNativeLibrary
         if self.lib.mcs_abi_version() != capi.MCS_ABI_VERSION:
             raise RuntimeError("libmcs_hip.so ABI version mismatch")
         self.device = int(device)
         self.stream = int(stream)
         self.torch_tallies = torch_tallies
+        self.debug_finals = debug_finals
         self.h = ct.c_void_p(None)
         self._bound = None
 
@@ -50,6 +54,8 @@ class HipBackend:
             torch.cuda.set_device(self.device)
             self.stream = int(torch.cuda.current_stream(self.device).cuda_stream)
         self._chk(self.lib.mcs_create(ct.byref(self.P), self.device, ct.c_void_p(self.stream or None), ct.byref(self.h)))
+        if self.debug_finals:
+            self._chk(self.lib.mcs_set_debug_finals(self.h, 1))
         if self.torch_tallies:
             dev = torch.device("cuda", self.device)
             t_f = torch.zeros(self.layout.total, dtype=torch.float64, device=dev)
@@ -122,10 +128,37 @@ class HipBackend:
     def pop_size(self) -> int:
         return int(self.lib.mcs_pop_size(self.h))
 
-    def run_pcut(self, i_pcut, i_prt_offset) -> int:
+    def run_pcut(self, i_pcut, i_prt_offset, i_prt_stride: int = 1) -> int:
+        """Local particle k has the global 0-based index i_prt_offset + k * i_prt_stride."""
         ns = ct.c_int64(0)
-        self._chk(self.lib.mcs_run_pcut(self.h, i_pcut, i_prt_offset, ct.byref(ns)))
+        self._chk(self.lib.mcs_run_pcut_strided(self.h, i_pcut, i_prt_offset, i_prt_stride, ct.byref(ns)))
+        self._n_saved_last = int(ns.value)
         return int(ns.value)
+
+    def set_retro_cap(self, cap: int):
+        self._chk(self.lib.mcs_set_retro_cap(self.h, int(cap)))
+
+    # -- multi-GPU new_pcut: saved particles out (to be all-gathered), global split slice in
+    def export_saved(self, cap: int):
+        """(gidx int64[cap], f64[8, cap], meta int32[cap]) torch CUDA tensors; the first n_saved columns are
+        the saved particles of the last run_pcut in index order (mcs_saved_export)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        gidx = torch.zeros(cap, dtype=torch.int64, device=dev)
+        f64 = torch.zeros((8, cap), dtype=torch.float64, device=dev)
+        meta = torch.zeros(cap, dtype=torch.int32, device=dev)      # the packed uint32 word, bit pattern kept
+        torch.cuda.current_stream(self.device).synchronize()
+        self._chk(self.lib.mcs_saved_export(self.h, cap, ct.c_void_p(gidx.data_ptr()), ct.c_void_p(f64.data_ptr()),
+                                            ct.c_void_p(meta.data_ptr())))
+        return gidx, f64, meta
+
+    def import_split(self, f64, meta, n_parents: int, i_mult: int, first: int, stride: int, n_local: int):
+        """New local population = elements first + k*stride of the global split of the parents (mcs_split_import)."""
+        import torch
+        assert f64.is_cuda and f64.is_contiguous() and meta.is_contiguous() and f64.shape[0] == 8
+        torch.cuda.current_stream(self.device).synchronize()
+        self._chk(self.lib.mcs_split_import(self.h, n_parents, f64.shape[1], ct.c_void_p(f64.data_ptr()),
+                                            ct.c_void_p(meta.data_ptr()), i_mult, first, stride, n_local))
 
     def run_pcut_host(self, i_pcut, pop: Population, i_prt_offset=0):
         """The literal drop-in call (host buffers in, saved arrays out)."""
@@ -146,6 +179,8 @@ class HipBackend:
         return saved, l_save
 
     def finals(self):
+        if not self.debug_finals:
+            raise RuntimeError("finals() needs HipBackend(..., debug_finals=True)")
         n = self.pop_size()
         reason = np.zeros(n, np.int32); helix = np.zeros(n, np.int32); retro = np.zeros(n, np.int32)
         ptot = np.zeros(n); x = np.zeros(n)

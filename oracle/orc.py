@@ -46,7 +46,8 @@ def load(math: str = "det", capi=None):
         "orc_begin_iteration": (i32, [vp, i32]),
         "orc_begin_species": (i32, [vp, i32, i32, dbl, dbl, dbl, dbl, dbl]),
         "orc_set_fluxes": (i32, [vp, dp, dp, dp]),
-        "orc_run_pcut": (i32, [vp, i32, i64, i64, soa_p, soa_p, u8p, i64p, i32]),
+        "orc_run_pcut": (i32, [vp, i32, i64, i64, i64, soa_p, soa_p, u8p, i64p, i32]),
+        "orc_set_retro_cap": (i32, [vp, i64]),
         "orc_finals": (i32, [vp, i64, i32p, i32p, i32p, dp, dp]),
         "orc_read_tallies": (i32, [vp, dp, i64p]),
         "orc_write_tallies": (i32, [vp, dp, i64p]),
@@ -146,18 +147,53 @@ class OracleBackend:
     def pop_size(self):
         return self.pop.n
 
-    def run_pcut(self, i_pcut, i_prt_offset):
+    def run_pcut(self, i_pcut, i_prt_offset, i_prt_stride=1):
         n = self.pop.n
+        self._idx = (int(i_prt_offset), int(i_prt_stride))
         self.saved = self.capi.Population(n)
         self.l_save = np.zeros(n, dtype=np.uint8)
         ns = ct.c_int64(0)
         si, so = self.pop.soa(), self.saved.soa()
-        self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, ct.byref(si), ct.byref(so),
+        self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, i_prt_stride, ct.byref(si), ct.byref(so),
                                         self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), ct.byref(ns), self.nthreads))
         return int(ns.value)
 
     def get_saved(self):
         return self.saved, self.l_save
+
+    def set_retro_cap(self, cap):
+        self._chk(self.lib.orc_set_retro_cap(self.h, int(cap)))
+
+    # -- multi-rank new_pcut (the CPU twin of mcs_saved_export / mcs_split_import, for the gloo tests of the driver)
+    def export_saved(self, cap):
+        import torch
+        F = self.capi.F64_FIELDS
+        idx = np.flatnonzero(self.l_save)
+        n = len(idx)
+        assert cap >= n
+        gidx = np.zeros(cap, np.int64); f64 = np.zeros((8, cap)); meta = np.zeros(cap, np.int32)
+        first, stride = self._idx
+        gidx[:n] = first + idx * stride
+        for r, f in enumerate(F):
+            f64[r, :n] = getattr(self.saved, f)[idx]
+        s = self.saved
+        meta[:n] = (s.grid[idx] & 0xffff) | ((s.tcut[idx] & 0xff) << 16) | (s.downstream[idx].astype(np.int64) << 24) | \
+                   (s.inj[idx].astype(np.int64) << 25)
+        return torch.from_numpy(gidx), torch.from_numpy(f64), torch.from_numpy(meta)
+
+    def import_split(self, f64, meta, n_parents, i_mult, first, stride, n_local):
+        F = self.capi.F64_FIELDS
+        f64 = f64.numpy(); meta = meta.numpy().astype(np.int64)
+        par = (first + np.arange(n_local, dtype=np.int64) * stride) // i_mult
+        assert n_local == 0 or par[-1] < n_parents
+        out = self.capi.Population(n_local)
+        for r, f in enumerate(F):
+            getattr(out, f)[:] = f64[r, par]
+        out.weight[:] = f64[0, par] / float(i_mult)
+        m = meta[par]
+        out.grid[:] = m & 0xffff; out.tcut[:] = (m >> 16) & 0xff
+        out.downstream[:] = (m >> 24) & 1; out.inj[:] = (m >> 25) & 1
+        self.pop = out
 
     def finals(self):
         n = self.pop.n

@@ -19,11 +19,14 @@ def main():
     # "oracle": CPU oracle over gloo; "hip-gloo": HIP backend, all ranks on GPU 0, CUDA tensors over
     # gloo (rehearses the device-side merge on a one-GPU box); "hip": one GPU per rank over RCCL
     dist.init_process_group("nccl" if backend_kind == "hip" else "gloo", rank=rank, world_size=world)
-    two_species = len(sys.argv) > 5 and sys.argv[5] == "2"
+    # further arguments: "2" (two species) and key=value options: itrs=, gather_max=, skew_max=
+    two_species = "2" in sys.argv[5:]
+    opt = dict(a.split("=", 1) for a in sys.argv[5:] if "=" in a)
+    n_itrs = int(opt.get("itrs", 2))
     kw = {}
     if two_species:
         kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)], energy_transfer_frac=0.1)
-    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2, **kw)
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=n_itrs, **kw)
     prob = mcs.inputs.build_problem(cfg)
     if backend_kind == "oracle":
         import orc
@@ -37,10 +40,12 @@ def main():
         dev = torch.device("cuda", local)
     be.create(prob)
     comm = mcs.driver.Comm(True, dev)
-    res = mcs.driver.run(prob, be, comm, n_itrs=2, max_pcuts=npc)
+    res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, max_pcuts=npc, gather_max=int(opt.get("gather_max", 1 << 17)),
+                         skew_max=float(opt.get("skew_max", 1.1)))
     if rank == 0:
         np.savez(out, f=res.tallies_f64, i=res.tallies_i64,
-                 stats=np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in res.stats]))
+                 stats=np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in res.stats]),
+                 n_use_max=np.array([s.n_use_max for s in res.stats]), split=np.array([s.split for s in res.stats]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -44,7 +44,7 @@ def oracle_backend(prob, math="det", nthreads=1):
 
 def hip_backend(prob):
     from mcs_amd import hip_backend as hb
-    be = hb.HipBackend(0)
+    be = hb.HipBackend(0, debug_finals=True)
     be.create(prob)
     return be
 

@@ -1,6 +1,7 @@
 """The multi-GPU path of the host driver, rehearsed on CPU: world_size 2 and 3 over gloo
-with the CPU oracle as backend must reproduce the single-process run (contiguous particle
-shards, global RNG keys, all-gather of n_saved, one sum-all-reduce of the tallies)."""
+with the CPU oracle as backend must reproduce the single-process run (particle shards with
+global RNG keys, all-gather of n_saved, the two forms of the cross-rank new_pcut, one
+sum-all-reduce of the tallies)."""
 import os
 import socket
 import subprocess
@@ -34,15 +35,23 @@ def _launch(world, out, N, npc, extra=()):
                 p.kill()
 
 
-def _single(N, npc, two=False):
+def _single(N, npc, two=False, n_itrs=2):
     kw = {}
     if two:
         kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)], energy_transfer_frac=0.1)
-    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2, **kw)
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=n_itrs, **kw)
     prob = mcs.inputs.build_problem(cfg)
     be = orc.OracleBackend(mcs.capi, "det", 1)
     be.create(prob)
-    return prob, mcs.driver.run(prob, be, None, n_itrs=2, max_pcuts=npc)
+    return prob, mcs.driver.run(prob, be, None, n_itrs=n_itrs, max_pcuts=npc)
+
+
+def _check_equal(prob, got, ref):
+    stats_ref = np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in ref.stats])
+    assert np.array_equal(got["stats"], stats_ref)              # same populations at every pcut
+    assert np.array_equal(got["i"], ref.tallies_i64)            # same steps, crossings, exits
+    from conftest import assert_tallies_close
+    assert_tallies_close(mcs.capi.Layout(prob.params), got["f"], ref.tallies_f64, rtol=1e-12)
 
 
 @pytest.mark.parametrize("world,two", [(2, False), (3, False), (2, True)])
@@ -51,10 +60,31 @@ def test_sharded_run_equals_single_process(tmp_path, world, two):
     out = str(tmp_path / f"w{world}.npz")
     _launch(world, out, N, npc, ("2",) if two else ())
     prob, ref = _single(N, npc, two)
+    _check_equal(prob, np.load(out), ref)
+
+
+@pytest.mark.parametrize("gather_max", [1 << 17, 40])
+def test_late_pcuts_are_balanced_across_ranks(tmp_path, gather_max):
+    """The whole iteration on 3 ranks.  In the late pcuts a handful of particles is saved and each is
+    replicated hundreds of times (src/cuts.jl:42); every rank must still carry a third of that
+    population (max/mean <= 1.01), and the run must equal the single-process one.  With
+    gather_max = 40 the early pcuts (many saved, evenly spread) take the local split and the
+    switch local -> gather is exercised; with the default every pcut gathers."""
+    world, N = 3, 1500
+    out = str(tmp_path / "late.npz")
+    _launch(world, out, N, 45, ("itrs=1", f"gather_max={gather_max}"))
+    prob, ref = _single(N, 45, n_itrs=1)
     got = np.load(out)
-    stats_ref = np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in ref.stats])
-    assert np.array_equal(got["stats"], stats_ref)              # same populations at every pcut
-    assert np.array_equal(got["i"], ref.tallies_i64)            # same steps, crossings, exits
-    L = mcs.capi.Layout(prob.params)
-    from conftest import assert_tallies_close
-    assert_tallies_close(L, got["f"], ref.tallies_f64, rtol=1e-12)
+    _check_equal(prob, got, ref)
+    st, n_use_max, split = got["stats"], got["n_use_max"], got["split"]
+    n_use, n_saved = st[:, 3], st[:, 4]
+    assert n_saved.min() == 0 and ((n_saved > 0) & (n_saved <= 5)).any()      # the iteration ran out; a late pcut had <= 5 parents
+    if gather_max == 40:
+        assert (split == "local").any() and (split == "gather").any()
+    for j in range(1, len(st)):
+        if split[j - 1] == "gather":            # population j was dealt out r, r+W, r+2W, ...
+            assert n_use_max[j] == -(-n_use[j] // world)
+            if n_use[j] >= 1000:
+                assert n_use_max[j] * world <= 1.01 * n_use[j]
+        else:                                   # local split: within the accepted skew
+            assert n_use_max[j] * world <= 1.1 * 1.001 * n_use[j] + world

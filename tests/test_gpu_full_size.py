@@ -1,0 +1,143 @@
+"""BASELINE configs at their full sizes on the GPU, through the C ABI.
+
+config[1] (10^6 protons, one iteration, all 45 pcuts): against the committed reduction of ONE full
+run of the CPU oracle (tests/golden/full_1e6.npz, made by tests/golden/make_golden_full.py): integer
+tallies and population sizes equal, every binned spectrum within 1e-11 of its maximum.
+
+config[2]'s population (10^7 particles) and config[1]'s again: size-independent properties checked in
+EVERY pcut the iteration reaches -- the late ones included, where the whole population is 10^5..10^7
+replicas of one or two saved particles piling onto single histogram bins.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, mcs, make_problem, oracle_backend, hip_backend, start_species, bits
+
+pytestmark = pytest.mark.gpu
+TALLY_RTOL = 1e-11
+
+
+def _load_reducer():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(ROOT, "tests", "golden", "make_golden_full.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.reduce_tallies
+
+
+def test_config1_full_size_vs_oracle_fixture():
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "full_1e6.npz"))
+    N = 1_000_000
+    prob = make_problem(N)
+    hb = hip_backend(prob)
+    res = mcs.driver.run(prob, hb, None, n_itrs=1)
+    hb.destroy()
+    got = _load_reducer()(mcs.capi.Layout(prob.params), res.tallies_f64, res.tallies_i64, res.stats)
+    assert np.array_equal(got["stats"], fix["stats"])                 # n_pts_use, n_saved, i_mult of all pcuts
+    assert np.array_equal(got["tallies_i64"], fix["tallies_i64"])     # crossings per zone, exits by reason, steps, draws
+    assert int(fix["stats"][:, 2].min()) == 0 and len(fix["stats"]) >= 30
+    worst = ("", 0.0)
+    for k in fix.files:
+        if k in ("stats", "tallies_i64", "meta"):
+            continue
+        a, b = got[k], fix[k]
+        assert a.shape == b.shape, k
+        if k.endswith("_idx"):
+            assert np.array_equal(a, b), k
+            continue
+        scale = float(np.max(np.abs(b)))
+        if scale == 0.0:
+            assert not np.any(a), k
+            continue
+        err = float(np.max(np.abs(a - b))) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= TALLY_RTOL, f"{k}: max|gpu - oracle| / max|oracle| = {err:.3e}"
+    print(f"config[1] at 1e6: {len(fix.files) - 3} binned arrays within {TALLY_RTOL}; worst {worst[0]} {worst[1]:.2e}; {fix['meta']}")
+
+
+def _property_run(N, n_prefix=4096, prefix_pcuts=5):
+    """One species through every pcut it reaches.  Per pcut: (i) every particle ends in exactly one way and the
+    saved flags are the reason-0 particles; (ii) the counters' exits equal the particles that ended; (iii) the first
+    n_prefix particles equal the oracle's bit for bit while the prefix stays aligned (pcuts 1-4 save everybody);
+    (iv) the split population is i_mult copies of each saved particle, in order, with weight / i_mult.  At the end:
+    weight is conserved through all splits, the upstream-escape tallies carry exactly the weight of the particles
+    that escaped upstream (LDS-staged and wave-reduced tallies at full size), no zone search failed."""
+    prob = make_problem(N)
+    hb = hip_backend(prob)
+    start_species(hb, prob)
+    ng, IC = prob.n_grid, mcs.capi.IC
+    pop = hb.get_population()
+    w_in = float(pop.weight.sum())
+    ob = oracle_backend(prob, nthreads=8)
+    start_species(ob, prob)
+    ob.set_population(pop.slice(0, n_prefix))
+    w_out = w_esc_up = 0.0
+    n_done = n_up = 0
+    reached = 0
+    I_prev = hb.read_tallies()[1]
+    for ip in range(1, len(prob.pcuts) + 1):
+        n_use = pop.n
+        ns = hb.run_pcut(ip, 0)
+        reached = ip
+        f = hb.finals()
+        saved, l_save = hb.get_saved()
+        assert int(l_save.sum()) == ns and np.array_equal(f["reason"] == 0, l_save == 1), f"pcut {ip}"
+        assert f["reason"].min() >= 0 and f["reason"].max() <= 4
+        ended = f["reason"] != 0
+        w_out += float(pop.weight[ended].sum())
+        up = f["reason"] == 2
+        w_esc_up += float(pop.weight[up].sum()); n_up += int(up.sum())
+        n_done += int(ended.sum())
+        I = hb.read_tallies()[1]
+        d = I - I_prev; I_prev = I
+        assert sum(int(d[ng + IC[f"REASON{r}"]]) for r in range(1, 5)) == int(ended.sum()), f"pcut {ip}"
+        assert int(d[ng + IC["REASON0"]]) == ns and int(ended.sum()) + ns == n_use
+        assert int(d[ng + IC["STEPS_HELIX"]]) == int(np.minimum(f["helix"], 10000).astype(np.int64).sum())
+        assert int(d[ng + IC["STEPS_RETRO"]]) == int(f["retro"].astype(np.int64).sum())
+        if ip <= prefix_pcuts:
+            ob.run_pcut(ip, 0)
+            fo = ob.finals()
+            for k in fo:
+                assert np.array_equal(bits(f[k][:n_prefix]), bits(fo[k])), f"pcut {ip}: prefix {k}"
+            if ip < prefix_pcuts:
+                assert ns == n_use      # pcuts 1-4 save everybody: i_mult == 1 keeps the prefix aligned
+                ob.new_pcut(1)
+        if ns == 0:
+            break
+        im = max(N // ns, 1)
+        assert hb.new_pcut(im) == ns * im
+        pop = hb.get_population()
+        src = np.flatnonzero(l_save)
+        o = np.unique(np.concatenate([np.arange(0, pop.n, 7), np.arange(max(pop.n - 1000, 0), pop.n)]))   # a sample of the new indices
+        par = src[o // im]
+        for fld in pop.fields():
+            want = getattr(saved, fld)[par]
+            if fld == "weight":
+                want = want / float(im)
+            assert np.array_equal(bits(getattr(pop, fld)[o]), bits(want)), f"pcut {ip}: split field {fld} (i_mult {im}, {ns} parents)"
+    assert reached >= 30, "the iteration should run into the late pcuts"
+    w_left = float(pop.weight.sum()) if ns else 0.0
+    assert abs(w_out + w_left - w_in) < 1e-9 * w_in
+    T, I = hb.read_tallies()
+    L = mcs.capi.Layout(prob.params)
+    assert int(I[ng + IC["ZONE_FAIL"]]) == 0 and int(I[ng + IC["RETRO_CAP"]]) == 0
+    assert sum(int(I[ng + IC[f"REASON{r}"]]) for r in range(1, 5)) == n_done
+    assert int(I[ng + IC["REASON2"]]) == n_up
+    # reason-2 weight reaches esc_flux (LDS scalar staging) and esc_num_eff (LDS per-bin staging) exactly once
+    assert abs(float(L.view(T, "esc_flux")[0]) - w_esc_up) <= 1e-10 * max(w_esc_up, 1e-300)
+    assert abs(float(L.view(T, "esc_num_eff").sum()) - w_esc_up) <= 1e-10 * max(w_esc_up, 1e-300)
+    hb.destroy(); ob.destroy()
+    return reached, n_done
+
+
+def test_config1_properties_every_pcut_1e6():
+    reached, n_done = _property_run(1_000_000)
+    print(f"1e6 protons: {reached} pcuts reached, {n_done} exits")
+
+
+def test_config2_population_properties_every_pcut_1e7():
+    reached, n_done = _property_run(10_000_000)
+    print(f"1e7 protons: {reached} pcuts reached, {n_done} exits")

@@ -9,7 +9,7 @@ cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations
 prob = m.inputs.build_problem(cfg)
 bes = []
 for k in range(K):
-    b = hip_backend.HipBackend(0); b.create(prob); bes.append(b)
+    b = hip_backend.HipBackend(0, debug_finals=True); b.create(prob); bes.append(b)
 res = [None] * K
 def work(k, it):
     # one iteration (i_iter = it) on backend k

@@ -14,7 +14,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 NPC = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
 prob = m.inputs.build_problem(cfg)
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 ob = orc.OracleBackend(m.capi, "det", nthreads=8); ob.create(prob)
 
 # 1. math

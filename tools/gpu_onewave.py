@@ -9,7 +9,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 big = 20000
 cfg = m.inputs.Config(N_PTS_INJ=big, N_PTS_PCUT=big, N_PTS_PCUT_HI=big)
 prob = m.inputs.build_problem(cfg)
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 hb.begin_iteration(1)
 inj = m.inputs.init_pop_host(prob, 1)
 hb.begin_species(1, 1, 1.0, 1.0, prob.pmax, 1.0, 1.0)

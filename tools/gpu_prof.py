@@ -13,7 +13,7 @@ from mcs_amd import hip_backend
 N = int(sys.argv[1]); NPC = int(sys.argv[2]); FIRST = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
 prob = m.inputs.build_problem(cfg)
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 hb.begin_iteration(1)
 inj = m.inputs.init_pop_host(prob, 1)
 hb.begin_species(1, 1, 1.0, 1.0, prob.pmax, 1.0, 1.0)

@@ -15,7 +15,7 @@ if MOD:
     x = prob.x_grid_cm; up = x < 0
     ux = prob.ux.copy(); ux[up] = prob.ux[1] * (1 - 0.3 * np.exp(x[up] / (50.0 * prob.rg0)))
     prob.ux = ux; prob.utot = np.hypot(prob.ux, prob.uz); prob.gam_sf = 1 / np.sqrt(1 - (prob.utot / C) ** 2)
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 if blocks: hb.set_launch(blocks, 256)
 hb.begin_iteration(1)
 inj = m.inputs.init_pop_host(prob, 1)

@@ -10,7 +10,7 @@ ME_MP = m.constants.ME / m.constants.MP
 cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, radiation_losses=True, energy_transfer_frac=0.1,
                       species=[m.inputs.Species(1.0, 1.0, 1e6, 1.0), m.inputs.Species(ME_MP, -1.0, 1e6, 1.0)])
 prob = m.inputs.build_problem(cfg)
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 res = m.driver.run(prob, hb, n_itrs=1)
 ng = prob.n_grid; IC = m.capi.IC
 prev = 0

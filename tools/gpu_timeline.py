@@ -9,7 +9,7 @@ from mcs_amd import hip_backend
 N = int(sys.argv[1]); PC = [int(x) for x in sys.argv[2].split(",")]
 BLOCKS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 prob = m.inputs.build_problem(m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N))
-hb = hip_backend.HipBackend(0); hb.create(prob)
+hb = hip_backend.HipBackend(0, debug_finals=True); hb.create(prob)
 if BLOCKS: hb.set_launch(BLOCKS, 256)
 hb.begin_iteration(1)
 inj = m.inputs.init_pop_host(prob, 1)
