@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=60000)
     ap.add_argument("--cpu-sample-1t", type=int, default=3000, help="particles of the single-thread CPU leg (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--smooth", action="store_true", help="replace the shock profile after every iteration (smooth_grid_par): config[2]'s loop")
     args = ap.parse_args()
 
     import torch
@@ -137,10 +138,12 @@ def main():
     marks = {}
 
     def on_species_end(i_iter, i_ion, G_f, G_i):
-        # called at the end of each iteration's (single) species: iteration boundary
         ng = prob.n_grid
         IC = mcs.capi.IC
         marks[i_iter] = (time.perf_counter(), int(G_i[ng + IC["STEPS_HELIX"]] + G_i[ng + IC["STEPS_RETRO"]]))
+
+    def on_iteration_end(i_iter):
+        # the iteration boundary: after ion_finalize (K4: dN/dp, pressures) and iter_finalize (+ the profile update)
         if i_iter == args.warmup:
             barrier()
             marks["t0"] = time.perf_counter()
@@ -148,7 +151,13 @@ def main():
     if args.warmup == 0:
         barrier()
         marks["t0"] = time.perf_counter()
-    res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, on_species_end=on_species_end)
+    # the whole i_iter body of src/main_loops.jl:52-391 is timed: init_pop, every pcut (K1 + K2), the merge of the tallies,
+    # ion_finalize's consumers on the device (K4) and iter_finalize; --smooth also replaces the shock profile after every
+    # iteration (smooth_grid_par), as in BASELINE config[2] -- the headline keeps the single unmodified shock of config[1]
+    # (the stock mc_in.toml has smooth-shocks = false)
+    sm = mcs.iter_finalize.SmoothingConfig(smooth_shocks=args.smooth)
+    res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, on_species_end=on_species_end, on_iteration_end=on_iteration_end,
+                         smoothing=sm)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - marks["t0"]
@@ -187,7 +196,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: 1e6 protons per GPU, single unmodified gamma0=5 shock, "
-                                   "45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration",
+                                   "45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration "
+                                   "(init_pop, 45 x (transport + new_pcut), tally merge, ion_finalize consumers, iter_finalize"
+                                   + (", profile smoothing" if args.smooth else "") + ")",
                        "particles_per_gpu": args.particles, "particles_total": n_global,
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"particle shards x{world}, all-gather(n_saved)/pcut, all-reduce(tallies)/iter"},

@@ -7,10 +7,11 @@ Only what the hot path needs lives here:
   driver.py    the iteration/species/pcut nest around the batched kernel
   hip_backend.py  the one and only compute backend (no CPU fallback)
   consumers.py  host tables + call order of the tally consumers (ion_finalize: dN/dp, pressures)
+  iter_finalize.py  iter_finalize + smooth_grid_par: the profile update between iterations (BASELINE config[2])
 
 The directory name contains a dot, so it is loaded through `_mcs_loader.load()`
 (repo root) under the module name `mcs_amd`.
 """
-from . import constants, capi, inputs, driver, consumers  # noqa: F401
+from . import constants, capi, inputs, driver, consumers, iter_finalize  # noqa: F401
 
-__all__ = ["constants", "capi", "inputs", "driver", "consumers"]
+__all__ = ["constants", "capi", "inputs", "driver", "consumers", "iter_finalize"]

@@ -60,6 +60,8 @@ class RunResult:
     stats: List[PcutStat]
     steps_helix: int
     steps_retro: int
+    iter_finals: list = dataclasses.field(default_factory=list)   # [(i_iter, IterFinal, IonFinal)] when run(finalize=True)
+    iter_state: object = None     # iter_finalize.IterState after the last iteration (run(finalize=True))
     local_steps: list = dataclasses.field(default_factory=list)   # [(i_iter, i_ion, helix + retro steps made by THIS rank's kernels)]
 
 
@@ -116,13 +118,24 @@ def shard_range(n: int, rank: int, world: int):
 
 def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[int] = None,
         max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
-        verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1) -> RunResult:
+        verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
+        finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
+        first_iter: int = 1, iter_state=None) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
     run_pcut/new_pcut/export_saved/import_split/pop_size/read_tallies/write_tallies/
     last_kernel_ms (HipBackend in hip_backend.py; tests inject the CPU oracle's).
     gather_max / skew_max: see the module docstring (multi-rank new_pcut).
+    finalize: close every iteration as the reference does (src/main_loops.jl:324-391): `ion_finalize`'s dN/dp and
+    thermo_calcs on the device-resident histograms (K4, consumers.py) and `iter_finalize` (iter_finalize.py).
+    smoothing: an iter_finalize.SmoothingConfig; with smooth_shocks the profile tables of `prob` are replaced after
+    every iteration (smooth_grid_par) and uploaded again (mcs_set_grid / mcs_set_cuts) -- BASELINE config[2]'s loop.
+    Rank 0 computes the update from the merged tallies and broadcasts the tables, so that every rank transports its
+    particles through bit-identical profiles.
+    first_iter / iter_state: run iterations first_iter .. first_iter + n_itrs - 1 (the iteration number enters the
+    RNG keys and indexes the per-iteration tallies), carrying the iter_finalize state of an earlier call
+    (RunResult.iter_state) -- lets a caller step through the loop one iteration at a time.
     """
     import torch
 
@@ -146,12 +159,19 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     from .capi import IC as _IC
     i_h, i_r = P.n_grid + _IC["STEPS_HELIX"], P.n_grid + _IC["STEPS_RETRO"]
     steps_seen = 0      # the step counters are never reset: this rank's running total
+    iter_finals = []
+    if smoothing is not None:
+        finalize = True
+    if finalize:
+        from . import consumers, iter_finalize as itf
+        sm = smoothing if smoothing is not None else itf.SmoothingConfig(smooth_shocks=False)
+        it_state = iter_state if iter_state is not None else itf.IterState.create(prob, sm, P.n_itrs)
 
     def tview(t, name):
         o = L.offsets[name]
         return t[o:o + int(np.prod(L.shapes[name]))]
 
-    for i_iter in range(1, n_itrs + 1):
+    for i_iter in range(first_iter, first_iter + n_itrs):
         backend.begin_iteration(i_iter)
         if multi and not is_root:
             if dev_t is not None:
@@ -271,7 +291,34 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             if on_species_end is not None:
                 on_species_end(i_iter, i_ion, G_f, G_i)
 
+        if finalize:
+            # ion_finalize of the last species (quirk Q2: only its fluxes and pressures reach iter_finalize) and
+            # iter_finalize, on rank 0, whose device buffers hold the merged tallies
+            changed = False
+            if is_root:
+                ion_fin = consumers.ion_finalize(prob, backend, len(cfg.species))
+                fin = itf.iter_finalize(prob, it_state, sm, i_iter, G_f, L, ion_fin.P_psd_par, ion_fin.P_psd_perp,
+                                        ion_fin.energy_density_psd)
+                iter_finals.append((i_iter, fin, ion_fin))
+                changed = fin.profile_changed
+            if multi and sm.smooth_shocks:
+                tabs = torch.from_numpy(np.stack([prob.ux, prob.gam_sf, prob.utot, prob.beta_ef, prob.gam_ef, prob.btot]))
+                dev = comm.device if comm.dist.get_backend() == "nccl" else None
+                tabs = tabs.to(dev) if dev is not None else tabs
+                comm.dist.broadcast(tabs, src=0)
+                tabs = tabs.cpu().numpy()
+                for k, name in enumerate(("ux", "gam_sf", "utot", "beta_ef", "gam_ef", "btot")):
+                    getattr(prob, name)[:] = tabs[k]
+                changed = True
+            if changed:
+                itf.populate_eps_target(prob)        # src/main_loops.jl:76-81, top of the next iteration
+                backend.set_grid(prob)
+                backend.set_cuts(prob)
+            if on_iteration_end is not None:
+                on_iteration_end(i_iter)
+
     ng = P.n_grid
     from .capi import IC
     return RunResult(G_f, G_i, per_species, stats,
-                     int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]), local_steps)
+                     int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]), iter_finals,
+                     it_state if finalize else None, local_steps)

@@ -61,8 +61,15 @@ class HipBackend:
             t_f = torch.zeros(self.layout.total, dtype=torch.float64, device=dev)
             t_i = torch.zeros(self.layout.n_i64, dtype=torch.int64, device=dev)
             self.bind_torch_tallies(t_f, t_i)
+        self.set_grid(prob)
+        self.set_cuts(prob)
+
+    def set_grid(self, prob):
+        """The grid tables of src/main_loops.jl:255-260 (again after every profile update, iter_finalize.py)."""
         tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in prob.grid_tables()]
         self._chk(self.lib.mcs_set_grid(self.h, len(tabs[0]), *[_dp(t) for t in tabs]))
+
+    def set_cuts(self, prob):
         pc, tc, xs, inj, eps = (np.ascontiguousarray(a, dtype=np.float64) for a in
                                 (prob.pcuts, prob.tcuts, prob.x_spec, prob.inj_fracs, prob.eps_target))
         self._chk(self.lib.mcs_set_cuts(self.h, len(pc), _dp(pc), len(tc), _dp(tc), len(xs), _dp(xs), _dp(inj), _dp(eps)))

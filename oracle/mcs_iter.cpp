@@ -1,0 +1,206 @@
+// mcs_iter.cpp -- CPU twin of montecarloscattering.jl_amd/iter_finalize.py.  TEST INFRASTRUCTURE ONLY.
+//
+// An independent C++ restatement of the reference's per-iteration profile update:
+//   upstream_fluxes        src/initializers.jl:513-615
+//   q_esc_calcs            src/q_esc_calcs.jl:11-125
+//   set_Γ_adiab_grid!      src/iter_finalize.jl:128-146
+//   smooth_grid_par        src/smoothers.jl:54-348   (the state-changing part; mc_grid.dat output is reporting)
+//   new_velocity_profile   src/smoothers.jl:351-571  (relativistic and classical)
+//   smooth_profile!        src/smoothers.jl:583-604
+// Where the product takes the closed-form roots of the momentum / energy equations, this twin runs the Newton
+// iteration the reference intends (`Roots.Newton()` from x0 = γ₀β₀·1e-4; as committed the reference passes no
+// derivative and would throw -- deviation S1 in iter_finalize.py), with the analytic derivative, to convergence.
+// The two must agree to rounding: tests/test_iter_finalize.py.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../include/mcs.h"
+
+namespace {
+const double CC = MCS_C, MP = MCS_MP, KB = MCS_KB, PI = 3.141592653589793;
+const double BETA_REL_FL = 0.02;   // src/parameters.jl:30
+
+template <class F>
+double newton(F f_df, double x0) {
+  double x = x0;
+  for (int it = 0; it < 10000; ++it) {     // grid_smoothing_maxitrs, src/smoothers.jl:14
+    double f, df;
+    f_df(x, f, df);
+    const double dx = f / df;
+    x -= dx;
+    if (std::fabs(dx) <= 1e-15 * std::fabs(x)) break;
+  }
+  return x;
+}
+
+// src/smoothers.jl:583-604; y[0..n-1] = zones 1..n_grid
+void smooth_profile(std::vector<double>& y) {
+  const int n = (int)y.size();
+  for (int i = n - 1; i >= 1; --i)
+    if (y[i - 1] < y[i]) y[i - 1] = y[i];
+  std::vector<double> d(y);
+  d[1] = (2 * y[0] + y[1] + y[2]) / 4;
+  for (int i = 2; i <= n - 3; ++i) d[i] = (y[i - 1] + y[i] + y[i + 1]) / 3;
+  d[n - 2] = (y[n - 3] + y[n - 2] + 2 * y[n - 1]) / 4;
+  for (int i = 1; i <= n - 2; ++i) y[i] = d[i];
+}
+}  // namespace
+
+extern "C" {
+
+// src/initializers.jl:513-615.  out = {F_px, F_pz, F_energy}
+int orc_upstream_fluxes(int n_ions, const double* n0, const double* T0, const double* m, double B0, double theta_deg, double u0,
+                        double b0, double g0, double* out) {
+  double P0 = 0, rho0 = 0;
+  for (int i = 0; i < n_ions; ++i) { P0 += n0[i] * T0[i]; rho0 += n0[i] * m[i]; }
+  P0 *= KB;
+  const double Gs = 5.0 / 3.0;
+  const double e0 = rho0 * CC * CC + 1 / (Gs - 1) * P0;
+  const double Bx = B0 * std::cos(theta_deg * PI / 180), Bz = B0 * std::sin(theta_deg * PI / 180);
+  if (b0 >= BETA_REL_FL) {
+    out[0] = (g0 * b0) * (g0 * b0) * (e0 + P0) + P0 + g0 * g0 * ((b0 * B0) * (b0 * B0) + Bz * Bz - Bx * Bx) / (8 * PI);
+    out[1] = -g0 * Bx * Bz / (4 * PI);
+    out[2] = CC * (g0 * g0 * b0 * (e0 + P0) + g0 * g0 * b0 * Bz * Bz / (4 * PI)) - g0 * u0 * rho0 * CC * CC;
+  } else {
+    const double Xi = Gs / (Gs - 1);
+    out[0] = rho0 * u0 * u0 * (1 + b0 * b0) + P0 * (1 + Xi * b0 * b0) + Bz * Bz / (8 * PI);
+    out[1] = -Bx * Bz / (4 * PI);
+    out[2] = rho0 * u0 * u0 * u0 * (1 + 1.25 * b0 * b0) / 2 + P0 * u0 * Xi * (1 + b0 * b0) + u0 * Bz * Bz / (4 * PI);
+  }
+  return 0;
+}
+
+// src/q_esc_calcs.jl: out = the function's two return values in ITS order (energy, p_x); the caller at
+// src/iter_finalize.jl:37 binds them to (q_esc_cal_pₓ, q_esc_cal_energy) -- swapped as written, replicated by both sides.
+int orc_q_esc_calcs(double Gamma, double r_comp, double r_RH, int n_ions, const double* n0, const double* T0, const double* m,
+                    double u0, double b0, double g0, double u2, double b2, double g2, double* out) {
+  out[0] = out[1] = 0.0;
+  if (r_comp == r_RH) return 0;
+  const double Gf = Gamma / (Gamma - 1);
+  double P0 = 0, rho0 = 0;
+  for (int i = 0; i < n_ions; ++i) { P0 += n0[i] * T0[i]; rho0 += n0[i] * m[i]; }
+  P0 *= KB;
+  if (b0 >= BETA_REL_FL) {
+    const double q_fac = CC * std::sqrt((1 + b0) / 2);
+    const double F_px = g0 * g0 * b0 * b0 * (rho0 * CC * CC + 2.5 * P0) + P0;
+    const double F_en = g0 * g0 * u0 * (rho0 * CC * CC + 2.5 * P0);
+    const double aux = g2 * g2 * (q_fac * b2 * b2 - u2);
+    const double rho2 = rho0 * g0 * b0 / (g2 * b2);
+    const double P2 = (q_fac * F_px - F_en - aux * rho2 * CC * CC) / (q_fac + Gf * aux);
+    const double Q_px = F_px - (g2 * b2) * (g2 * b2) * (rho2 * CC * CC + Gf * P2) - P2;
+    const double Q_en = Q_px * q_fac;
+    out[0] = Q_en / (F_en - g0 * u0 * rho0 * CC * CC);
+    out[1] = Q_px / F_px;
+  } else {
+    const double F_px = rho0 * u0 * u0 + P0;
+    const double F_en = rho0 * u0 * u0 * u0 / 2 + 2.5 * P0 * u0;
+    const double rho2 = rho0 * g0 * b0 / (g2 * b2);
+    const double P2 = F_px - rho2 * u2 * u2;
+    const double Q_en = F_en - rho0 * u0 * u2 * u2 / 2 - P2 * u2 * Gf;
+    out[0] = Q_en / F_en;
+    out[1] = 0.0;
+  }
+  return 0;
+}
+
+// src/iter_finalize.jl:128-146; Gamma_grid[n_grid][2] row-major
+int orc_set_gamma_grid(double* Gamma_grid, int i_iter, int n_grid, const double* x_grid_cm /*n_grid+2*/, double Gamma2_RH,
+                       const double* P_par, const double* P_perp, const double* e_dens) {
+  for (int i = 0; i < n_grid; ++i) {
+    if (i_iter == 1) Gamma_grid[2 * i] = x_grid_cm[i + 1] <= 0 ? 5.0 / 3.0 : Gamma2_RH;
+    else Gamma_grid[2 * i] = Gamma_grid[2 * i + 1];
+    Gamma_grid[2 * i + 1] = e_dens[i] == 1.0e-99 ? 1.0e-99 : 1 + (P_par[i] + P_perp[i]) / e_dens[i];
+  }
+  return 0;
+}
+
+// src/smoothers.jl:54-348 (+ :351-571).  Tables have n_grid+2 entries (index == Julia offset index); the per-zone arrays
+// Gamma_post, pxx_flux, energy_flux, P_tot_MC are zones 1..n_grid at [0..n_grid-1].  Entries 1..n_grid of ux, gam_sf, utot,
+// beta_ef, gam_ef, btot are overwritten; ux_new_out (n_grid, may be null) receives the profile BEFORE the averaging with the
+// old one.
+int orc_smooth_grid_par(int n_grid, int i_shock, const double* x_grid_rg, double* ux, double* gam_sf, double* utot, double* beta_ef,
+                        double* gam_ef, double* btot, const double* theta, const double* Gamma_post, const double* pxx_flux,
+                        const double* energy_flux, const double* P_tot_MC, double q_px, double q_en, double F_px, double F_en,
+                        double n0_aa, double u0, double b0, double g0, double u2, double smmoe, double smpfp, double prof_weight_fac,
+                        double x_art_start_rg, double B0, double bturb_comp_frac, double bfield_amp, double* ux_new_out) {
+  const int n = n_grid;
+  const bool rel = b0 >= BETA_REL_FL;
+  const double Qpx = rel ? q_px * pxx_flux[0] : 0.0;
+  const double Qen = q_en * energy_flux[0];
+  std::vector<double> vpx(n), ven(n);
+  double avg_px = 0, avg_en = 0;
+  for (int i = 1; i <= n; ++i) {
+    const double u = ux[i], bu = u / CC, g = gam_sf[i], g2 = g * g, gb = g * bu;
+    const double Gp = Gamma_post[i - 1], Xi = Gp / (Gp - 1);
+    const double B = btot[i], Bx = B * std::cos(theta[i]), Bz = B * std::sin(theta[i]);
+    const double pxx_EM = gb * gb / (8 * PI) * B * B + g2 / (8 * PI) * (Bz * Bz - Bx * Bx);
+    const double en_EM = g2 / (4 * PI) * bu * Bz * Bz;
+    if (rel) {
+      const double dens = g0 * b0 / (g * bu) * n0_aa;
+      const double p_px = (pxx_flux[i - 1] - gb * gb * dens * MP * CC * CC) / (1 + gb * gb * Xi);
+      const double p_loc = (1 - smpfp) * p_px + smpfp * P_tot_MC[i - 1];
+      const double a_m = g0 * b0 * n0_aa * (MP * CC * CC + p_loc * Xi / dens);
+      double r = newton([&](double x, double& f, double& df) { f = F_px - Qpx - pxx_EM - a_m * x - p_loc; df = -a_m; }, g0 * b0 * 1.0e-4);
+      vpx[i - 1] = r / std::sqrt(1 + r * r) * CC;
+      const double a_e = CC * (dens * MP * CC * CC + Xi * p_loc);
+      r = newton([&](double x, double& f, double& df) {
+        const double gg = std::sqrt(1 + x * x);
+        f = F_en - Qen - en_EM - x * gg * a_e;
+        df = -a_e * (gg + x * x / gg);
+      }, g0 * b0 * 1.0e-4);
+      ven[i - 1] = r / std::sqrt(1 + r * r) * CC;
+    } else {
+      const double rho0 = n0_aa * MP;
+      const double p_px = (pxx_flux[i - 1] - rho0 * u0 * u * (1 + bu * bu)) / (1 + bu * bu * Xi);
+      const double p_loc = (1 - smpfp) * p_px + smpfp * P_tot_MC[i - 1];
+      vpx[i - 1] = CC * newton([&](double b, double& f, double& df) {
+        f = F_px - Qpx - pxx_EM - rho0 * u0 * (b * CC) * (1 + b * b) - (1 + b * b * Xi) * p_loc;
+        df = -(rho0 * u0 * CC * (1 + 3 * b * b) + 2 * b * Xi * p_loc);
+      }, u0 / CC * 1.0e-4);
+      ven[i - 1] = newton([&](double v, double& f, double& df) {
+        const double b = v / CC;
+        f = F_en - Qen - en_EM - 0.5 * rho0 * u0 * v * v * (1 + 1.25 * b * b) - Xi * p_loc * v * (1 + b * b);
+        df = -(rho0 * u0 * v * (1 + 2.5 * b * b) + Xi * p_loc * (1 + 3 * b * b));
+      }, u0 * 1.0e-4);
+    }
+    if (i > n - 10) { avg_px += vpx[i - 1]; avg_en += ven[i - 1]; }
+  }
+  if (rel) { smooth_profile(vpx); smooth_profile(ven); }
+  avg_px /= 10; avg_en /= 10;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<double>& a = pass ? ven : vpx;
+    const double avg = pass ? avg_en : avg_px;
+    const double sc = (u0 - u2) / (a[0] - avg);
+    for (int i = 1; i <= n; ++i) {
+      a[i - 1] = sc * (a[i - 1] - avg) + u2;
+      if (x_grid_rg[i] >= 0) a[i - 1] = u2;
+    }
+  }
+  if (!rel) { smooth_profile(vpx); smooth_profile(ven); }
+  std::vector<double> un(n);
+  for (int i = 0; i < n; ++i) un[i] = (1 - smmoe) * vpx[i] + smmoe * ven[i];
+  if (x_art_start_rg < 0) {
+    int it = 0;
+    while (it < n + 2 && !(x_grid_rg[it] > x_art_start_rg)) ++it;
+    it -= 1;
+    const double sc = -(un[it - 1] - un[n - 1]) / std::atan(x_grid_rg[it]);
+    for (int i = it; i <= i_shock; ++i) un[i - 1] = -std::atan(x_grid_rg[i]) * sc + un[n - 1];
+  }
+  if (ux_new_out) for (int i = 0; i < n; ++i) ux_new_out[i] = un[i];
+  for (int i = 1; i <= n; ++i) {
+    const double u = (un[i - 1] + prof_weight_fac * ux[i]) / (1 + prof_weight_fac);
+    ux[i] = u;
+    gam_sf[i] = 1 / std::sqrt(1 - (u / CC) * (u / CC));
+    utot[i] = u;
+    beta_ef[i] = (u0 - u) / (CC - u0 * u / CC);
+    gam_ef[i] = 1 / std::sqrt(1 - beta_ef[i] * beta_ef[i]);
+    const double z = (g0 * u0) / (gam_sf[i] * u);
+    const double comp = 1 + (std::sqrt(1.0 / 3 + 2.0 / 3 * z * z) - 1) * bturb_comp_frac;
+    const double amp = 1 + (comp - 1) * bfield_amp;
+    btot[i] = B0 * amp;
+  }
+  return 0;
+}
+
+}  // extern "C"

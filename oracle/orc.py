@@ -61,6 +61,11 @@ def load(math: str = "det", capi=None):
         "orc_transform_p_PSP": (None, [vp] + [dbl] * 5 + [dp, dp, dp]),
         "orc_bin_momentum": (i32, [vp, dbl]),
         "orc_bin_angle": (i32, [vp, dbl, dbl]),
+        # oracle/mcs_iter.cpp: the CPU twin of montecarloscattering.jl_amd/iter_finalize.py
+        "orc_upstream_fluxes": (i32, [i32, dp, dp, dp, dbl, dbl, dbl, dbl, dbl, dp]),
+        "orc_q_esc_calcs": (i32, [dbl, dbl, dbl, i32, dp, dp, dp, dbl, dbl, dbl, dbl, dbl, dbl, dp]),
+        "orc_set_gamma_grid": (i32, [dp, i32, i32, dp, dbl, dp, dp, dp]),
+        "orc_smooth_grid_par": (i32, [i32, i32, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp] + [dbl] * 16 + [dp]),
     }
     if capi is not None:
         cin_p = ct.POINTER(capi.McsConsumerIn)
@@ -101,8 +106,14 @@ class OracleBackend:
         self.h = self.lib.orc_create(ct.byref(self.P))
         if not self.h:
             raise RuntimeError(self.lib.orc_last_error().decode())
+        self.set_grid(prob)
+        self.set_cuts(prob)
+
+    def set_grid(self, prob):
         tabs = [np.ascontiguousarray(t) for t in prob.grid_tables()]
         self._chk(self.lib.orc_set_grid(self.h, len(tabs[0]), *[_dp(t) for t in tabs]))
+
+    def set_cuts(self, prob):
         self._keep = [np.ascontiguousarray(a, dtype=np.float64) for a in
                       (prob.pcuts, prob.tcuts, prob.x_spec, prob.inj_fracs, prob.eps_target)]
         pc, tc, xs, inj, eps = self._keep

@@ -1,0 +1,64 @@
+"""BASELINE config[2]'s multi-iteration loop with an evolving shock profile, GPU against the CPU oracle.
+
+Each iteration is run on both sides from IDENTICAL tables and must agree as every single-iteration test does
+(integers equal, binned spectra within 1e-11).  The profile update computed from the GPU's tallies (K4 consumers
+on the device + iter_finalize.py) and the one computed from the oracle's (CPU consumers + the same host update,
+which tests/test_iter_finalize.py checks against its C++ twin) must agree to the stated tolerance -- they start from tallies that differ in the
+order of their atomic adds, and the pressure that drives the update is a small difference of large fluxes; then
+both sides continue from ONE profile (the GPU-derived one), so that the next iteration is again bit-comparable.
+"""
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+from conftest import mcs, orc, assert_tallies_close
+
+pytestmark = pytest.mark.gpu
+itf = mcs.iter_finalize
+TABLES = ("ux", "gam_sf", "utot", "beta_ef", "gam_ef", "btot")
+PROFILE_RTOL = 1e-8
+
+
+def test_config2_three_iterations_with_profile_update():
+    from mcs_amd import hip_backend as hbm
+    N, n_itrs = 20_000, 3
+    sm = itf.SmoothingConfig(smooth_shocks=True)
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=n_itrs)
+    pg, po = mcs.inputs.build_problem(cfg), mcs.inputs.build_problem(cfg)
+    hb = hbm.HipBackend(0); hb.create(pg)
+    ob = orc.OracleBackend(mcs.capi, "det", nthreads=16); ob.create(po)
+    sg = so = None
+    worst = 0.0
+    for it in range(1, n_itrs + 1):
+        before = pg.ux.copy()
+        assert all(np.array_equal(getattr(pg, k), getattr(po, k)) for k in TABLES)        # same inputs
+        rg = mcs.driver.run(pg, hb, None, n_itrs=1, smoothing=sm, first_iter=it, iter_state=sg); sg = rg.iter_state
+        ro = mcs.driver.run(po, ob, None, n_itrs=1, smoothing=sm, first_iter=it, iter_state=so); so = ro.iter_state
+        assert np.array_equal(rg.tallies_i64, ro.tallies_i64), f"iteration {it}"
+        assert [(s.n_pts_use, s.n_saved, s.i_mult) for s in rg.stats] == [(s.n_pts_use, s.n_saved, s.i_mult) for s in ro.stats]
+        assert_tallies_close(hb.layout, rg.tallies_f64, ro.tallies_f64, 1e-11)
+        (_, fg, ig), = rg.iter_finals
+        (_, fo, io), = ro.iter_finals
+        for name in ("P_psd_par", "P_psd_perp", "energy_density_psd"):                    # K4 on the device vs the CPU consumers
+            a, b = getattr(ig, name), getattr(io, name)
+            assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), (it, name)
+        assert abs(fg.Gamma_downstream / fo.Gamma_downstream - 1) < 1e-10
+        # the two updated profiles
+        for k in TABLES:
+            a, b = getattr(pg, k), getattr(po, k)
+            err = float(np.max(np.abs(a / b - 1)))
+            worst = max(worst, err)
+            assert err <= PROFILE_RTOL, f"iteration {it}: table {k} differs by {err:.2e}"
+        assert not np.array_equal(pg.ux, before), f"iteration {it}: the profile did not change"
+        n = pg.n_grid
+        assert np.all(np.diff(pg.ux[1:n + 1]) <= 1e-12 * pg.params.u0)
+        # one profile for both from here on
+        for k in TABLES:
+            getattr(po, k)[:] = getattr(pg, k)
+        itf.populate_eps_target(po)
+        ob.set_grid(po); ob.set_cuts(po)
+    print(f"3 iterations, N = {N}: GPU- and oracle-derived profiles agree to {worst:.2e} (bound {PROFILE_RTOL})")
+    # the device really transports through the NEW tables: an unmodified-profile run of iteration 3 differs
+    assert pg.ux[pg.params.i_shock - 3] < pg.params.u0 * 0.999
+    hb.destroy(); ob.destroy()
