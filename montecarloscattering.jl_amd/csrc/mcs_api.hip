@@ -79,6 +79,7 @@ struct mcs_ctx {
   long long idx_first = 0, idx_stride = 1;   // global index of local particle k in that run: idx_first + k * idx_stride
   bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
   int retro_cap = MCS_RETRO_CAP;
+  int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
   // finals
   int32_t *f_reason = nullptr, *f_helix = nullptr, *f_retro = nullptr; double *f_ptot = nullptr, *f_x = nullptr;
   long long f_cap = 0;
@@ -245,6 +246,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_DEFER_K"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 40) c->defer_k = std::atoi(e); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
   c->device = device;
@@ -570,6 +572,7 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
   a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride;
   a.retro_cap = c->retro_cap;
+  a.defer_k = c->defer_k;
   // iseed_mod - i_prt, src/particle_loop.jl:35-40
   a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
                                      (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +

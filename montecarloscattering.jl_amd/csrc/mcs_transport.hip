@@ -49,6 +49,9 @@
 #define MCS_REFILL_MIN 12       // idle lanes a wave collects before it claims new particles: a refill stalls the wave for a memory latency,
                                 // and parked particles resume in batches of that size (final kernel: 6 -> 458 ms, 8 -> 451, 12 -> 442, 16 -> 444)
 #endif
+#ifndef MCS_DEFER_K
+#define MCS_DEFER_K 8           // lanes with pending rare work a wave collects before it enters the rare region (see `enter` in the loop)
+#endif
 #ifndef MCS_MERGE_POLL_MASK
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
 #endif
@@ -839,7 +842,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
-  p.flags = F_RS | F_RM | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0);
+  p.flags = F_RS | F_RM | F_NOPARK | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0);   // (F_NOPARK: the new particle's first Code Blocks run now)
   p.n_ovr = 0u;
   refresh_time(a, h, p);
   p.npush = 0;
@@ -1296,8 +1299,7 @@ __shared__ unsigned int S_mstate[2];    // per SIMD pair: 0 open, 1 donated, 2 c
 __shared__ unsigned int S_mcount[2];    // particles in the mailbox
 
 template <int STRIDE>
-__device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x, bool moved,
-                                            double phi_prev) {
+__device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& rng, long long k, int evw, double phi_prev) {
   const double v[30] = {p.weight, p.ptot_pf, p.pb_pf, p.p_perp, p.gam_pf, p.x, p.x_old, p.phi, p.prp, p.acctime, p.xn_per, p.dphi,
                         p.gyro_denom, p.gyro_rad, p.gyro_rad_tot, p.gyro_period, p.t_step, p.rp_val, p.cm_val, p.rg_val, p.x_dt,
                         p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, phi_prev, 0.0};
@@ -1305,7 +1307,7 @@ __device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& 
   for (int j = 0; j < 30; ++j) mb[j * STRIDE] = v[j];
   mb[30 * STRIDE] = __longlong_as_double(k);
   const int gridpack = p.i_grid | (p.i_grid_old << 8) | (p.ig3 << 16) | (p.tcut << 24);
-  const int bits = p.ovr_inc | ((int)p.downstream << 1) | ((int)p.inj << 2) | ((int)ev << 3) | ((int)ev_x << 4) | ((int)moved << 5);
+  const int bits = p.ovr_inc | ((int)p.downstream << 1) | ((int)p.inj << 2) | ((evw & 7) << 3);
   mb[31 * STRIDE] = __hiloint2double(p.flags, (int)p.n_ovr);
   mb[32 * STRIDE] = __hiloint2double(gridpack, p.helix);
   mb[33 * STRIDE] = __hiloint2double(p.n_retro, bits);
@@ -1313,8 +1315,7 @@ __device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& 
   mb[35 * STRIDE] = __hiloint2double((int)rng.n, 0);
 }
 template <int STRIDE, bool COHERENT>
-__device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
-                                           double& phi_prev) {
+__device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, long long& k, int& evw, double& phi_prev) {
   // COHERENT: the wave reads back what it stored to global memory earlier -- agent-scope loads, past the L1
   auto LD = [&](int j) -> double {
     if (COHERENT) return __hip_atomic_load(mb + j * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1334,20 +1335,17 @@ __device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, lo
   p.i_grid = gridpack & 0xff; p.i_grid_old = (gridpack >> 8) & 0xff; p.ig3 = (gridpack >> 16) & 0xff; p.tcut = (gridpack >> 24) & 0xff;
   p.n_retro = __double2hiint(w3);
   const int bits = __double2loint(w3);
-  p.ovr_inc = bits & 1; p.downstream = (bits >> 1) & 1; p.inj = (bits >> 2) & 1; ev = (bits >> 3) & 1; ev_x = (bits >> 4) & 1;
-  moved = (bits >> 5) & 1;
+  p.ovr_inc = bits & 1; p.downstream = (bits >> 1) & 1; p.inj = (bits >> 2) & 1; evw = (bits >> 3) & 7;
   rng.k0 = (uint32_t)__double2hiint(w4); rng.k1 = (uint32_t)__double2loint(w4);
   rng.n = (uint32_t)__double2hiint(w5);
   p.npush = 0;
 }
 
-__device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, const Rng& rng, long long k, bool ev, bool ev_x,
-                                         bool moved, double phi_prev) {
-  state_store<MCS_MB_SLOTS>(&S_evf[box][0][0] + r, p, rng, k, ev, ev_x, moved, phi_prev);
+__device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, const Rng& rng, long long k, int evw, double phi_prev) {
+  state_store<MCS_MB_SLOTS>(&S_evf[box][0][0] + r, p, rng, k, evw, phi_prev);
 }
-__device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, bool& ev, bool& ev_x, bool& moved,
-                                        double& phi_prev) {
-  state_load<MCS_MB_SLOTS, false>(&S_evf[box][0][0] + r, p, rng, k, ev, ev_x, moved, phi_prev);
+__device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, int& evw, double& phi_prev) {
+  state_load<MCS_MB_SLOTS, false>(&S_evf[box][0][0] + r, p, rng, k, evw, phi_prev);
 }
 static_assert(MCS_PARK_WORDS == MCS_MB_WORDS, "one state layout");
 
@@ -1445,10 +1443,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0;
   p.i_grid = 0; p.i_grid_old = 0; p.ig3 = 0; p.helix = 0; p.tcut = 1; p.n_retro = 0; p.downstream = false; p.inj = false;
   rng.init(0ull);
-  bool active = false, exhausted = false;
-  bool ev = false;        // the last move of this lane needs slow_post
-  bool ev_x = false;      // the last move of this lane left its zone
-  bool moved = false;     // this lane's particle has made a move since it was loaded
+  // act: -1 while the lane holds a live particle, 0 while it is idle (an all-ones / all-zeros word, so that the loop header
+  // masks the pending bits with one v_and; hipcc keeps a `bool` as a byte in a VGPR and spends two VALU per ballot on it)
+  int act = 0;
+#define active (act != 0)
+  bool exhausted = false;
+  // what the last move of this lane's particle left pending, in ONE register (the loop header tests it together with
+  // p.flags): bit 0 "ev" the move needs slow_post, bit 1 "ev_x" the move left its zone, bit 2 "moved" the particle has
+  // made a move since it was loaded
+  int evw = 0;
   double phi_prev = 0.0;  // phase before the last move (the no-DSA retry loop needs it)
   long long k = -1;
   const unsigned lane = __lane_id();
@@ -1494,6 +1497,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   // while parked particles wait for a lane, else 64 (nothing left: the wave ends)
   unsigned refill_at = MCS_REFILL_MIN;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
+  unsigned defer_k = h.every_pass ? 1u : (unsigned)__builtin_amdgcn_readfirstlane(a->defer_k);      // 1 once the work counter is exhausted
   p.npush = 0;
   bool done = false;
   while (!done) {
@@ -1515,9 +1519,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const unsigned r = below(~act_mask);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's stores to the park buffer have landed
         if (!active && r < take) {
-          state_load<MCS_PARK_SLOTS, true>(park_ptr() + (n_parked - take + r), p, rng, k, ev, ev_x, moved, phi_prev);
+          state_load<MCS_PARK_SLOTS, true>(park_ptr() + (n_parked - take + r), p, rng, k, evw, phi_prev);
           p.flags |= F_NOPARK;
-          active = true;
+          act = -1;
         }
         n_parked -= take;
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1533,6 +1537,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         base = __shfl(base, leader);
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
+          defer_k = 1u;
           if (mrole != 0) mpoll_mask = MCS_MERGE_POLL_MASK;
 #ifdef MCS_PROF_TAIL
           if (lane == 0) S_ttgate[wv] = 1u;
@@ -1546,7 +1551,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           if (idx < n) {
             k = (long long)idx;
             load_particle(a, s, h, k, p, rng);
-            active = true; ev = false; ev_x = false; moved = false;
+            act = -1; evw = 0;
             // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
             // every outstanding store and no-return tally atomic)
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1561,8 +1566,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const unsigned long long idle_now = ~__builtin_amdgcn_ballot_w64(active);
         const unsigned r = below(idle_now);
         if (!active && r < cntm) {
-          mb_load(mpartner, r, p, rng, k, ev, ev_x, moved, phi_prev);
-          active = true;
+          mb_load(mpartner, r, p, rng, k, evw, phi_prev);
+          act = -1;
         }
         mrole = 0; mpoll_mask = ~0u;
       };
@@ -1591,14 +1596,14 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           } else if (nlive <= MCS_MB_SLOTS && nlive <= room) {
             // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
             drain_events(a, s, wv, lane, true); ev_pending = 0u;
-            if (active) mb_store(wv, below(__builtin_amdgcn_ballot_w64(active)), p, rng, k, ev, ev_x, moved, phi_prev);
+            if (active) mb_store(wv, below(__builtin_amdgcn_ballot_w64(active)), p, rng, k, evw, phi_prev);
             unsigned st = 2u;
             if (lane == 0) S_mcount[mpair] = (unsigned)nlive;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) st = atomicCAS(&S_mstate[mpair], 0u, 1u);
             st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
             if (st == 0u) {          // handed over: this wave is done
-              active = false; p.flags = 0; p.helix = 0; ev = false; ev_x = false;
+              act = 0; p.flags = 0; p.helix = 0; evw = 0;
             }
             mrole = 0; mpoll_mask = ~0u;     // (st == 2: the receiver had already left -- carry on alone)
           }
@@ -1620,15 +1625,30 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // ---- the one rare region (see the comment above move_and_detect)
     // (ev and ev_x are false for a particle that has not moved yet; F_NEARFEB is one of the flags)
     // (| and &: one condition, one conditional region -- && / || compile to nested exec-mask regions)
-    const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
-    PROF_LANES(13, active && (ev || ev_x || unusual));
+    // (pending-move bits and flags in one test; bits 0-1 of evw are clear for a particle that has not moved yet)
+    // (the helix cap is reported through the ev bit by the common pass, see below)
+    const int wi = (((evw & 3) | p.flags) | (h.every_pass ? 1 : 0)) & act;
+    const bool want = wi != 0;
+    PROF_LANES(13, want);
 #ifdef MCS_PROF_TAIL
-    const bool rare_any__ = PROF_GATE && __builtin_amdgcn_ballot_w64(active && (ev || ev_x || unusual)) != 0ull;
+    const bool rare_any__ = PROF_GATE && __builtin_amdgcn_ballot_w64(want) != 0ull;
     unsigned long long tt0__ = 0;
     if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
 #endif
     bool parked_now = false;
-    if (MCS_UNLIKELY(active & (ev | ev_x | unusual))) {
+    // ---- deferral.  Entering the rare region costs the WAVE ~1000 cycles whatever the number of lanes in it, and in the
+    // bulk of a launch some lane has a zone crossing pending in three passes out of four (2.4 lanes per entry): half of
+    // all VALU issue went into the region for two or three lanes.  A lane can wait: nothing of its particle changes
+    // while it is masked out of the common pass (state, RNG stream position and pending-event bits stay as they are), so
+    // its history -- every bit of it -- is the same whenever the region is finally entered.  The wave therefore enters
+    // only when MCS_DEFER_K lanes have work pending, or one that must not wait (a lane that needs the region in every
+    // pass -- the FEB zone -- or that has just been loaded or resumed, F_NOPARK); the waiting lanes sit out the common pass.
+    // After the work counter is exhausted nothing waits (defer_k = 1): the launch then waits for its longest histories;
+    // configurations with work in every pass (h.every_pass) never wait either.
+    const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want);
+    const unsigned long long m_urgent = __builtin_amdgcn_ballot_w64((wi & (F_NEARFEB | F_NOPARK)) != 0);
+    const bool enter = (m_urgent != 0ull) | ((unsigned)__popcll(m_want) >= defer_k);
+    if (MCS_UNLIKELY(want & enter)) {      // (one condition, one conditional region: `enter` is wave-uniform)
       PROF_ADD(12, 1);
 #ifdef MCS_PROF_TAIL
 #define TT_MARK(slot) do { const unsigned long long tn__ = __builtin_amdgcn_s_memtime(); if (PROF_GATE && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&S_prof[slot], tn__ - tm__); tm__ = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1636,6 +1656,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #else
 #define TT_MARK(slot) do { } while (0)
 #endif
+      const bool ev = (evw & 1) != 0, ev_x = (evw & 2) != 0, moved = (evw & 4) != 0;
+      [[maybe_unused]] const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
       const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
       int end = -1;
       // What is due, from the state the move left (the expressions of move_and_detect).  A lane with nothing but
@@ -1662,10 +1684,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if (full && moved && (p.flags & F_NOPARK) == 0 && p.helix < MCS_PARK_HELIX_MAX) {
           const unsigned slot = n_parked + below(__builtin_amdgcn_ballot_w64(true));
           if (slot < (unsigned)MCS_PARK_SLOTS) {
-            state_store<MCS_PARK_SLOTS>(park_ptr() + slot, p, rng, k, ev, ev_x, moved, phi_prev);
+            state_store<MCS_PARK_SLOTS>(park_ptr() + slot, p, rng, k, evw, phi_prev);
             parked_now = true;
             full = false;
-            active = false; ev = false; ev_x = false;
+            act = 0; evw = 0;
             p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
           }
         }
@@ -1746,28 +1768,34 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if (a->f_reason) {
           a->f_reason[k] = end; a->f_helix[k] = p.helix; a->f_retro[k] = p.n_retro; a->f_ptot[k] = p.ptot_pf; a->f_x[k] = p.x;
         }
-        active = false;
+        act = 0;
         p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
         TT_MARK(19);
       }
       }
     }
+    const bool frozen = want & !enter;  // waits for the region: sits out this pass
 #ifdef MCS_PROF_TAIL
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
     n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));     // (unconditional: no branch in the common pass)
-    // ---- the common pass, for every lane (idle lanes compute on stale state; nothing is stored)
-    p.helix += 1;
-    if (!h.dont_scatter) scattering(rng, p, kc);
-    {
-      const bool ds = p.downstream;
-      const double acc_new = p.acctime + t_clock * p.z_gef;
-      p.acctime = ds ? acc_new : p.acctime;
-      p.n_ovr += (unsigned)p.ovr_inc;
-      const bool ev_time = ds && p.acctime >= p.t_ev;
-      ev = move_and_detect(a, h, p, phi_prev, ev_x) | ev_time;
+    // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
+    if (!frozen) {
+      p.helix += 1;
+      if (!h.dont_scatter) scattering(rng, p, kc);
+      {
+        const bool ds = p.downstream;
+        const double acc_new = p.acctime + t_clock * p.z_gef;
+        p.acctime = ds ? acc_new : p.acctime;
+        p.n_ovr += (unsigned)p.ovr_inc;
+        const bool ev_time = ds && p.acctime >= p.t_ev;
+        bool x1;
+        // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
+        // due for such a lane and slow_pre ends the particle, quirk Q5)
+        const bool e1 = move_and_detect(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
+        evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
+      }
     }
-    moved = true;
   }
 
 #ifdef MCS_PROF
@@ -1820,6 +1848,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (w != 0.0) gadd_f64(&a->T[a->L.esc_num_eff + o], w);
   }
 }
+
+#undef active
 
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport(const KArgs* __restrict__ ka) {
   transport_body<false>(ka);

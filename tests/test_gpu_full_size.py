@@ -2,8 +2,8 @@
 
 config[1] (10^6 protons, one iteration, all 45 pcuts): against the committed reduction of ONE full
 run of the CPU oracle (tests/golden/full_1e6.npz, made by tests/golden/make_golden_full.py): integer
-tallies and population sizes equal, every binned spectrum within 1e-11 of its maximum (1e-10 for the three signed
-flux vectors, see FLUX_RTOL).
+tallies and population sizes equal, every binned spectrum within 1e-11 of its maximum (1e-10 for the flux vectors and
+scalar accumulators that sum 1e7..1e8 terms per entry, see LONG_SUM_RTOL).
 
 config[2]'s population (10^7 particles) and config[1]'s again: size-independent properties checked in
 EVERY pcut the iteration reaches -- the late ones included, where the whole population is 10^5..10^7
@@ -18,11 +18,14 @@ from conftest import ROOT, mcs, make_problem, oracle_backend, hip_backend, start
 
 pytestmark = pytest.mark.gpu
 TALLY_RTOL = 1e-11
-# the three flux vectors are sums of ~1e8 SIGNED terms per zone at this size (upstream- and downstream-going crossings
-# cancel to a tenth of their gross sum), accumulated in a different random order by the GPU's atomics and by the
-# threaded oracle: eps * sqrt(1e8) * 10 ~ 1e-11 of the result.  Measured 1.5e-11; bound 1e-10.  (The reference rounds
-# exactly these arrays to 13 digits for the same reason, src/iter_finalize.jl:46-54.)
-FLUX_RTOL = 1e-10
+# Arrays whose entries are sums of 1e7..1e8 terms at this size: the three flux vectors (signed terms per zone: upstream-
+# and downstream-going crossings cancel to a tenth of their gross sum) and the per-species / per-time-cut / per-momentum-
+# bin accumulators (esc_flux: 1.6e7 IDENTICAL weights, whose rounding errors do not average out but add up along whatever
+# order the adds take -- one serial sum in the oracle, per-block partial sums in LDS on the GPU).  Measured 1.5e-11 and
+# 2.7e-11; bound 1e-10.  (The reference rounds its fluxes to 13 digits for the same reason, src/iter_finalize.jl:46-54.)
+LONG_SUM_RTOL = 1e-10
+LONG_SUMS = ("pxx_flux", "pxz_flux", "energy_flux", "esc_flux", "px_esc_feb", "energy_esc_feb", "esc_energy_eff", "esc_num_eff",
+             "weight_coupled", "scalars")
 
 
 def _load_reducer():
@@ -60,7 +63,7 @@ def test_config1_full_size_vs_oracle_fixture():
         err = float(np.max(np.abs(a - b))) / scale
         if err > worst[1]:
             worst = (k, err)
-        tol = FLUX_RTOL if k in ("pxx_flux", "pxz_flux", "energy_flux") else TALLY_RTOL
+        tol = LONG_SUM_RTOL if k in LONG_SUMS else TALLY_RTOL
         assert err <= tol, f"{k}: max|gpu - oracle| / max|oracle| = {err:.3e}"
     print(f"config[1] at 1e6: {len(fix.files) - 3} binned arrays within {TALLY_RTOL}; worst {worst[0]} {worst[1]:.2e}; {fix['meta']}")
 

@@ -76,21 +76,30 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/mcs_transport-hip-amdgcn-amd-amdhsa-gfx950.s"
     kernel = sys.argv[2] if len(sys.argv) > 2 else "mcs_k_transport_plain"
     ins = parse(path, kernel)
-    # the particle loop: the first depth-1 loop header of the kernel body that encloses fp64 work; its common pass is
-    # the code laid out from the header to the first branch back to it (rare bodies are out of line: MCS_UNLIKELY)
-    headers = [i for i, (t, lab) in enumerate(ins) if lab and "Loop Header: Depth=1" in lab[1]]
+    # the particle loop: the depth-1 loop header with child loops (the rare code's loops); its common pass is the
+    # fall-through chain from the header -- conditional branches guard out-of-line rare code (MCS_UNLIKELY) or exec-mask
+    # regions that are entered, so they fall through; an unconditional s_branch is followed -- until the header comes again
+    label_at = {lab[0]: i for i, (t, lab) in enumerate(ins) if lab}
+    headers = [i for i, (t, lab) in enumerate(ins) if lab and "This Loop Header: Depth=1" in lab[1]]
     best = None
     for h in headers:
         name = ins[h][1][0]
-        for j in range(h, len(ins)):
-            m = re.match(r"s_cbranch_\w+\s+(\S+)", ins[j][0])
-            if m and m.group(1) == name:
-                n64 = sum(1 for t, _ in ins[h:j + 1] if "_f64" in t.split()[0])
-                if best is None or n64 > best[0]:
-                    best = (n64, h, j, name)
+        body, i, seen = [], h, set()
+        while i < len(ins) and i not in seen:
+            seen.add(i)
+            t, lab = ins[i]
+            if lab and lab[0] == name and body:
                 break
-    _, h, j, name = best
-    body = ins[h:j + 1]
+            body.append((t, lab))
+            m = re.match(r"s_branch\s+(\S+)", t)
+            if m:
+                i = label_at[m.group(1)]
+                continue
+            i += 1
+        n64 = sum(1 for t, _ in body if "_f64" in t.split()[0])
+        if best is None or n64 > best[0]:
+            best = (n64, name, body)
+    _, name, body = best
     hist = collections.Counter(classify(t) for t, _ in body)
     total = len(body)
     regions = [t for t, _ in body if t.startswith("s_cbranch")]
