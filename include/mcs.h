@@ -87,6 +87,9 @@ typedef struct mcs_params {
   int32_t use_custom_epsB, do_rad_losses, do_retro, do_tcuts;
   int32_t dont_DSA, dont_scatter, use_custom_frg;
   int32_t track_thermal;        /* A9: bin non-injected crossings on the fly */
+  int32_t state_fp32;           /* 0: fp64 particle state (the reference's precision).  1: the fp32-state variant of K1 --
+                                 * state and per-step arithmetic in fp32 in normalised units (p / m_p c, x / rg0, t c / rg0),
+                                 * population in HBM and all tallies fp64 (BASELINE config[4]; DESIGN.md "fp32-state variant") */
 } mcs_params;
 
 /* One particle population, struct-of-arrays, host side; element types follow the

@@ -44,6 +44,7 @@ class McsParams(ct.Structure):
         ("do_tcuts", ct.c_int32),
         ("dont_DSA", ct.c_int32), ("dont_scatter", ct.c_int32), ("use_custom_frg", ct.c_int32),
         ("track_thermal", ct.c_int32),
+        ("state_fp32", ct.c_int32),
     ]
 
 

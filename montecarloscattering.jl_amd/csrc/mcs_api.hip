@@ -18,6 +18,7 @@ extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st);
+hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
 hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st);
@@ -79,6 +80,7 @@ struct mcs_ctx {
   long long idx_first = 0, idx_stride = 1;   // global index of local particle k in that run: idx_first + k * idx_stride
   bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
   int retro_cap = MCS_RETRO_CAP;
+  bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
   int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
   // finals
   int32_t *f_reason = nullptr, *f_helix = nullptr, *f_retro = nullptr; double *f_ptot = nullptr, *f_x = nullptr;
@@ -246,6 +248,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_DEFER_K"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 40) c->defer_k = std::atoi(e); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
@@ -573,6 +576,7 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride;
   a.retro_cap = c->retro_cap;
   a.defer_k = c->defer_k;
+  a.tail_ring = c->tail_ring ? 1 : 0;
   // iseed_mod - i_prt, src/particle_loop.jl:35-40
   a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
                                      (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
@@ -588,7 +592,8 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   if (blocks <= 0) {
     // persistent lanes: fill the chip, never launch more lanes than particles
     const long long want = (n + threads - 1) / threads;
-    const long long full = (long long)c->n_cu * 2;     // two 256-thread blocks are resident per CU (76 KB of LDS each)
+    // two 256-thread blocks are resident per CU (78 KB of LDS each); the fp32-state kernel (27 KB, 119 VGPRs) fits four
+    const long long full = (long long)c->n_cu * (c->P.state_fp32 ? 4 : 2);
     blocks = (int)(want < full ? want : full);
     if (blocks < 1) blocks = 1;
   }
@@ -598,7 +603,11 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                      !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
-  if (n > 0) { HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream)); c->rep_dirty = true; }
+  if (n > 0) {
+    if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, blocks, 256, c->stream));
+    else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
+    c->rep_dirty = true;
+  }
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
   // independent count of the l_save flags next to the kernel's own n_saved counter, read back together

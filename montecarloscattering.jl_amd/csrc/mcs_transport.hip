@@ -182,9 +182,7 @@ __shared__ int S_nc[MCS_MAXNE];             // num_crossings staging
 __shared__ double S_evf[4][MCS_EV_F64][MCS_EV_CAP];
 __shared__ unsigned int S_evu[4][MCS_EV_CAP];
 __shared__ unsigned int S_evcur[4];         // per-wave stack height
-struct Lds {                                // kept as an (empty) handle so call sites read the same
-  static constexpr double* x = nullptr;
-};
+struct Lds {};                               // an empty handle: the tables are static LDS arrays, call sites pass it along
 
 // ---- particle state (registers) ---------------------------------------------------
 // The zone properties "of the current pass" (ux, uz, utot, gamma_sf, gamma_ef, sin/cos
@@ -411,18 +409,26 @@ __device__ __forceinline__ void refresh_scatter(CK* a, Pt& p, double aa, double 
   p.rp_val = rcp_refined(p.ptot_pf);
 }
 
-// src/scattering.jl:61-101: the per-step part (two draws, new pitch, phase adjustment); straight-line code
-__device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef& kc) {
+// The part of a scatter that depends on nothing but the particle's random stream: the two draws of block `blk` of the
+// stream (k0, k1) (src/scattering.jl:68,71) and sin / cos of the azimuth phi_scat = 2 pi U2 - pi (:71).  A function of
+// (key, draw index) alone, so it can be evaluated ahead of time and by any lane (see the tail ring in transport_body).
+__device__ __forceinline__ void scatter_draws(uint32_t k0, uint32_t k1, uint32_t blk, const mcsm::HotCoef& kc, double& U1,
+                                              double& s_ps, double& c_ps) {
+  uint32_t o0, o1, o2, o3;
+  philox_block(blk, 0u, 0u, 0u, k0, k1, o0, o1, o2, o3);
+  U1 = u64_to_unit(o0, o1);
+  const double U2 = u64_to_unit(o2, o3);
+  const double phi_scat = U2 * TWOPI_ - PI_;
+  mcsm::sincos_t(phi_scat, &s_ps, &c_ps, kc);
+}
+
+// src/scattering.jl:61-101: the per-step part (new pitch, phase adjustment) given the draw-dependent values; straight-line code
+__device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, double U1, double s_ps, double c_ps) {
   const double cos_max = p.cm_val;
   const double cos_old = div_r(p.pb_pf, p.ptot_pf, p.rp_val);      // == pb_pf / ptot_pf
   const double sin_old = div_r(p.p_perp, p.ptot_pf, p.rp_val);     // == p_perp / ptot_pf
-  double U1, U2;
-  rng.pair(U1, U2);
   const double cos_d = 1 - U1 * (1 - cos_max);
   const double sin_d = FSQRT(1 - cos_d * cos_d);
-  const double phi_scat = U2 * TWOPI_ - PI_;
-  double s_ps, c_ps;
-  mcsm::sincos_t(phi_scat, &s_ps, &c_ps, kc);
   const double cos_new = cos_old * cos_d + sin_old * sin_d * c_ps;
   double arg = 1 - cos_new * cos_new;
   if (arg < 0) arg = 0;
@@ -437,6 +443,14 @@ __device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef&
   const double adj = mcsm::asin_t(sd, kc);
   const double phi_p_new = sin_new != 0 ? phi_p_old + adj : phi_p_old;
   p.phi = phi_p_new - HALFPI_;
+}
+// the two draws of a scatter are indices n, n+1 = one Philox block
+__device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef& kc) {
+  double U1, s_ps, c_ps;
+  const uint32_t j = rng.n;
+  rng.n = j + 2u;
+  scatter_draws(rng.k0, rng.k1, j >> 1, kc, U1, s_ps, c_ps);
+  scattering_with(p, kc, U1, s_ps, c_ps);
 }
 
 // src/particle_loop.jl:639-650
@@ -506,7 +520,6 @@ __device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, d
   const int step = down ? 1 : -1;
   const int sign_fac = down ? 1 : -1;
   const bool inj_check = !down;
-  const int ng = P.n_grid;
   int i_pt = 0, jth = 0;
   if (inj) { i_pt = bin_momentum(a, ptot_sk); jth = bin_angle(a, px, ptot_sk); }
   const double f_pxx = sign_fac * px * weight * P.gam0 * P.u0;
@@ -1354,15 +1367,10 @@ __device__ __forceinline__ unsigned below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// PLAIN = the common configuration, decided by the host: scattering on, parallel field in every zone,
-// no custom eps_B, no energy transfer, no electron radiative losses, no downstream FEB, DSA on with
-// injection probability 1, ions, no x_spec detectors.  The flags are then compile-time constants: their
-// scalar branches and the code behind them disappear from that kernel.
-template <bool PLAIN>
-__device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
-  CK* a = (CK*)ka;
-  const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
-  Lds s;
+// Per-block set-up shared by the transport kernels: the grid tables (plus per-zone sin / cos theta_B and 1/(qB)) and the
+// time cuts into LDS, the staging arrays and counters cleared.  The caller synchronises.
+__device__ __forceinline__ void block_prologue(CK* a) {
+  const int ne = a->P.n_grid + 2, ntc = a->tb.n_tcuts;
   for (int i = threadIdx.x; i < ne; i += blockDim.x) {
     S_x[i] = a->tb.x_grid[i]; S_ux[i] = a->tb.ux[i]; S_uz[i] = a->tb.uz[i]; S_ut[i] = a->tb.utot[i];
     S_gsf[i] = a->tb.gsf[i]; S_gef[i] = a->tb.gef[i];
@@ -1394,6 +1402,62 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF) S_prof[threadIdx.x] = 0ull;
 #endif
+}
+
+// Per-block flush of the LDS staging (fluxes, crossings, counters, scalars, per-bin escape sums) into the tally buffers:
+// one global atomic per entry and block.  The caller has synchronised.
+__device__ __forceinline__ void block_flush(CK* a) {
+  const int ng = a->P.n_grid;
+  if (threadIdx.x < 3 && S_steps[threadIdx.x]) {   // one global atomic per block and counter
+    const int which = threadIdx.x == 0 ? MCS_IC_STEPS_HELIX : (threadIdx.x == 1 ? MCS_IC_STEPS_RETRO : MCS_IC_RNG_DRAWS);
+    gadd_u64(&a->I[ng + which], S_steps[threadIdx.x]);
+  }
+  if (threadIdx.x < MCS_IC_COUNT) {
+    const unsigned int c = g_ctr[threadIdx.x];
+    if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
+  } else if (threadIdx.x == MCS_IC_COUNT) {
+    const unsigned int c = g_ctr[MCS_IC_COUNT];
+    if (c) gadd_u64(a->n_saved, (unsigned long long)c);
+  } else if (threadIdx.x < MCS_IC_COUNT + 8) {
+    const int j = threadIdx.x - MCS_IC_COUNT - 1;
+    const double v = g_sc[j];
+    const int ion = a->i_ion - 1, iter = a->i_iter - 1;
+    long long off = a->L.scalars + j;
+    if (j == 4) off = a->L.esc_flux + ion;
+    else if (j == 5) off = a->L.px_esc_feb + ion + (long long)a->P.n_ions * iter;
+    else if (j == 6) off = a->L.energy_esc_feb + ion + (long long)a->P.n_ions * iter;
+    if (v != 0.0) gadd_f64(&a->T[off], v);
+  }
+  for (int i = threadIdx.x; i < ng; i += blockDim.x) {
+    const double v0 = S_fl[i], v1 = S_fl[MCS_MAXNE + i], v2 = S_fl[2 * MCS_MAXNE + i];
+    if (v0 != 0.0) gadd_f64(&a->T[a->L.pxx_flux + i], v0);
+    if (v1 != 0.0) gadd_f64(&a->T[a->L.pxz_flux + i], v1);
+    if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
+    const int c = S_nc[i];
+    if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
+  }
+  for (int i = threadIdx.x; i < MCS_NA_C; i += blockDim.x) {
+    const double w = S_wc[i];
+    if (w != 0.0) gadd_f64(&a->T[a->L.weight_coupled + i + (long long)MCS_NA_C * (a->i_ion - 1)], w);
+  }
+  for (int i = threadIdx.x; i <= MCS_PSD_MAX; i += blockDim.x) {
+    const long long o = i + (long long)(MCS_PSD_MAX + 1) * (a->i_ion - 1);
+    const double e = S_eff[0][i], w = S_eff[1][i];
+    if (e != 0.0) gadd_f64(&a->T[a->L.esc_energy_eff + o], e);
+    if (w != 0.0) gadd_f64(&a->T[a->L.esc_num_eff + o], w);
+  }
+}
+
+// PLAIN = the common configuration, decided by the host: scattering on, parallel field in every zone,
+// no custom eps_B, no energy transfer, no electron radiative losses, no downstream FEB, DSA on with
+// injection probability 1, ions, no x_spec detectors.  The flags are then compile-time constants: their
+// scalar branches and the code behind them disappear from that kernel.
+template <bool PLAIN>
+__device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
+  CK* a = (CK*)ka;
+  const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
+  Lds s;
+  block_prologue(a);
   __syncthreads();
 
   // Hot-loop constants are parked in VGPRs behind an opaque move: the compiler can then
@@ -1497,6 +1561,20 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   // while parked particles wait for a lane, else 64 (nothing left: the wave ends)
   unsigned refill_at = MCS_REFILL_MIN;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
+  // ---- tail ring.  After the work counter is exhausted a wave decays to a handful of live particles, and an instruction
+  // costs the wave the same with 1 lane enabled as with 64.  A third of the common pass -- the Philox block of the two
+  // draws, their conversion, sin / cos of the scattering azimuth: scatter_draws() -- depends on nothing but the
+  // particle's random stream (key, draw index), so the idle lanes compute it AHEAD: with L <= 32 live lanes, lane w
+  // evaluates block j = w mod D of the next D = 2^floor(log2(64 / L)) scatters of the (w / D)-th live particle, all in
+  // one pass of those ~115 instructions; the results sit in the free top of the wave's record stack (entries 128..191:
+  // at most 63 + 2 L <= 127 records are pending) and the live lane reads its three doubles back in each of the next D
+  // passes.  An entry is addressed by draw index (entry j <-> index rb + 2j), so draws taken in rare code in between
+  // (prob_return, the retro walk: whole blocks) just skip entries; a lane whose particle changes invalidates its batch.
+  // Same functions, same bits: per-particle results are unchanged.
+  bool ring_on = false;             // wave-uniform: the work counter is exhausted (and KArgs::tail_ring)
+  unsigned rb = 0u - 256u;          // draw index of entry 0 of this lane's batch; (rng.n - rb) / 2 >= ringD: no entry
+  unsigned rrow = 0u;               // first entry of this lane's batch
+  unsigned ringD = 1u;              // wave-uniform: entries per live lane in the current batch
   unsigned defer_k = h.every_pass ? 1u : (unsigned)__builtin_amdgcn_readfirstlane(a->defer_k);      // 1 once the work counter is exhausted
   p.npush = 0;
   bool done = false;
@@ -1509,6 +1587,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // pass), so the wave waits until MCS_REFILL_MIN lanes are idle.  With histories of a few hundred
     // passes (late pcuts) a lane idles every 3-4 passes and refilling each at once cost ~25 % of the time.
     const int n_idle = 64 - __popcll(act_mask);
+    unsigned Lh = 64u - (unsigned)n_idle;     // live lanes while this pass's rare region runs (housekeeping may add some)
     ++mtick;
     // (bitwise | on purpose: one scalar branch, not a chain of short-circuit branches)
     if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
@@ -1520,6 +1599,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's stores to the park buffer have landed
         if (!active && r < take) {
           state_load<MCS_PARK_SLOTS, true>(park_ptr() + (n_parked - take + r), p, rng, k, evw, phi_prev);
+          rb = rng.n - 256u;
           p.flags |= F_NOPARK;
           act = -1;
         }
@@ -1538,6 +1618,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
           defer_k = 1u;
+          ring_on = __builtin_amdgcn_readfirstlane(a->tail_ring) != 0;
           if (mrole != 0) mpoll_mask = MCS_MERGE_POLL_MASK;
 #ifdef MCS_PROF_TAIL
           if (lane == 0) S_ttgate[wv] = 1u;
@@ -1551,7 +1632,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           if (idx < n) {
             k = (long long)idx;
             load_particle(a, s, h, k, p, rng);
-            act = -1; evw = 0;
+            act = -1; evw = 0; rb = 0u - 256u;
             // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
             // every outstanding store and no-return tally atomic)
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1567,6 +1648,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const unsigned r = below(idle_now);
         if (!active && r < cntm) {
           mb_load(mpartner, r, p, rng, k, evw, phi_prev);
+          rb = rng.n - 256u;
           act = -1;
         }
         mrole = 0; mpoll_mask = ~0u;
@@ -1597,6 +1679,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
             drain_events(a, s, wv, lane, true); ev_pending = 0u;
             if (active) mb_store(wv, below(__builtin_amdgcn_ballot_w64(active)), p, rng, k, evw, phi_prev);
+            rb = rng.n - 256u;            // the mailbox has overwritten this wave's ring (it may have to carry on alone)
             unsigned st = 2u;
             if (lane == 0) S_mcount[mpair] = (unsigned)nlive;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1612,7 +1695,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       if (exhausted) refill_at = n_parked > 0u ? 1u : 64u;
       // nothing left: the loop ends after this pass (which computes on idle lanes and stores nothing) -- no jump
       // out of the middle of the loop, which costs the common pass a branch and half a dozen register copies
-      done = (__builtin_amdgcn_ballot_w64(active) == 0ull) & exhausted & (n_parked == 0u);
+      const unsigned long long am_hk = __builtin_amdgcn_ballot_w64(active);
+      Lh = (unsigned)__popcll(am_hk);
+      done = (am_hk == 0ull) & exhausted & (n_parked == 0u);
     }
     {
       [[maybe_unused]] const int na__ = __popcll(__builtin_amdgcn_ballot_w64(active));
@@ -1779,10 +1864,53 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
     n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));     // (unconditional: no branch in the common pass)
+    // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
+    bool got = false;
+    double rU1 = 0.0, rs = 0.0, rc = 0.0;
+    if (MCS_UNLIKELY(ring_on)) {
+      // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
+      const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+      const unsigned L = (unsigned)__popcll(am);
+      if ((L >= 1u) & (Lh <= 32u) & (n_parked == 0u)) {
+        unsigned jj = (rng.n - rb) >> 1;
+        if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
+          // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
+          const unsigned lg = 31u - (unsigned)__builtin_clz(64u / L);
+          const unsigned D = 1u << lg;
+          const unsigned rank = below(am);
+          if (active) {
+            S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
+            S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
+          }
+          const unsigned q = lane >> lg, jw = lane & (D - 1u);
+          const bool valid = q < L;
+          const unsigned qq = valid ? q : 0u;
+          const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq];
+          double eU1, es, ec;
+          scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
+          if (valid) { S_evf[wv][0][128u + lane] = eU1; S_evf[wv][1][128u + lane] = es; S_evf[wv][2][128u + lane] = ec; }   // entry q * D + jw == lane
+          if (active) { rb = rng.n; rrow = rank << lg; }
+          ringD = D;
+          jj = 0u;
+        }
+        const unsigned idx = (rrow + jj) & 63u;
+        rU1 = S_evf[wv][0][128u + idx]; rs = S_evf[wv][1][128u + idx]; rc = S_evf[wv][2][128u + idx];
+        got = true;
+      } else {
+        rb = rng.n - 256u;            // the top of the stack may be overwritten by records now: no batch survives
+      }
+    }
     // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
     if (!frozen) {
       p.helix += 1;
-      if (!h.dont_scatter) scattering(rng, p, kc);
+      if (!h.dont_scatter) {
+        double U1, s_ps, c_ps;
+        const uint32_t jd = rng.n;
+        rng.n = jd + 2u;
+        if (got) { U1 = rU1; s_ps = rs; c_ps = rc; }
+        else scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
+        scattering_with(p, kc, U1, s_ps, c_ps);
+      }
       {
         const bool ds = p.downstream;
         const double acc_new = p.acctime + t_clock * p.z_gef;
@@ -1809,44 +1937,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF && S_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], S_prof[threadIdx.x]);
 #endif
-  if (threadIdx.x < 3 && S_steps[threadIdx.x]) {   // one global atomic per block and counter
-    const int which = threadIdx.x == 0 ? MCS_IC_STEPS_HELIX : (threadIdx.x == 1 ? MCS_IC_STEPS_RETRO : MCS_IC_RNG_DRAWS);
-    gadd_u64(&a->I[ng + which], S_steps[threadIdx.x]);
-  }
-  if (threadIdx.x < MCS_IC_COUNT) {
-    const unsigned int c = g_ctr[threadIdx.x];
-    if (c) gadd_u64(&a->I[ng + threadIdx.x], (unsigned long long)c);
-  } else if (threadIdx.x == MCS_IC_COUNT) {
-    const unsigned int c = g_ctr[MCS_IC_COUNT];
-    if (c) gadd_u64(a->n_saved, (unsigned long long)c);
-  } else if (threadIdx.x < MCS_IC_COUNT + 8) {
-    const int j = threadIdx.x - MCS_IC_COUNT - 1;
-    const double v = g_sc[j];
-    const int ion = a->i_ion - 1, iter = a->i_iter - 1;
-    long long off = a->L.scalars + j;
-    if (j == 4) off = a->L.esc_flux + ion;
-    else if (j == 5) off = a->L.px_esc_feb + ion + (long long)a->P.n_ions * iter;
-    else if (j == 6) off = a->L.energy_esc_feb + ion + (long long)a->P.n_ions * iter;
-    if (v != 0.0) gadd_f64(&a->T[off], v);
-  }
-  for (int i = threadIdx.x; i < ng; i += blockDim.x) {
-    const double v0 = S_fl[i], v1 = S_fl[MCS_MAXNE + i], v2 = S_fl[2 * MCS_MAXNE + i];
-    if (v0 != 0.0) gadd_f64(&a->T[a->L.pxx_flux + i], v0);
-    if (v1 != 0.0) gadd_f64(&a->T[a->L.pxz_flux + i], v1);
-    if (v2 != 0.0) gadd_f64(&a->T[a->L.energy_flux + i], v2);
-    const int c = S_nc[i];
-    if (c) gadd_u64(&a->I[MCS_I_NUM_CROSSINGS + i], (unsigned long long)c);
-  }
-  for (int i = threadIdx.x; i < MCS_NA_C; i += blockDim.x) {
-    const double w = S_wc[i];
-    if (w != 0.0) gadd_f64(&a->T[a->L.weight_coupled + i + (long long)MCS_NA_C * (a->i_ion - 1)], w);
-  }
-  for (int i = threadIdx.x; i <= MCS_PSD_MAX; i += blockDim.x) {
-    const long long o = i + (long long)(MCS_PSD_MAX + 1) * (a->i_ion - 1);
-    const double e = S_eff[0][i], w = S_eff[1][i];
-    if (e != 0.0) gadd_f64(&a->T[a->L.esc_energy_eff + o], e);
-    if (w != 0.0) gadd_f64(&a->T[a->L.esc_num_eff + o], w);
-  }
+  block_flush(a);
 }
 
 #undef active
@@ -1868,6 +1959,8 @@ extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+#include "mcs_transport_f32.inc"
+
 extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_grid; (void)n_tcuts; return 0; }   // static LDS
 extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 

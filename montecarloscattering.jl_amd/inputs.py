@@ -110,6 +110,7 @@ class Config:
     grid_variant: str = "intended"      # "intended" | "verbatim" (reference quirk G1)
     track_thermal: bool = True
     abs_charge: bool = True             # quirk Q11: pass |Z| (the reference's signed electron charge makes t_step < 0)
+    state_fp32: bool = False            # the fp32-state variant of the transport kernel (BASELINE config[4])
 
 
 _TOML_KEYS = {
@@ -542,6 +543,7 @@ def build_problem(cfg: Config) -> Problem:
     P.do_rad_losses, P.do_retro, P.do_tcuts = int(cfg.radiation_losses), int(do_retro), int(do_tcuts)
     P.dont_DSA, P.dont_scatter, P.use_custom_frg = int(cfg.no_DSA), int(cfg.no_scatter), int(cfg.use_custom_frg)
     P.track_thermal = int(cfg.track_thermal)
+    P.state_fp32 = int(cfg.state_fp32)
 
     return Problem(cfg=cfg, params=P, x_grid_rg=x_grid_rg, x_grid_cm=x_grid_cm, ux=ux, uz=uz, utot=utot,
                    gam_sf=gsf, gam_ef=gef, beta_ef=bef, btot=bt, theta=theta, pcuts=pcuts, tcuts=tcuts,

@@ -78,3 +78,13 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(mcs.capi, "_LIB", None)
     with pytest.raises(mcs.capi.MissingNativeLibrary):
         mcs.capi.load_library()
+
+
+def test_kernel_register_allocation_is_as_documented():
+    """The build keeps the compiler's kernel-resource-usage remarks of mcs_transport.hip; the transport kernels must stay
+    inside the documented bounds (tools/check_resources.py: occupancy, VGPR spills, scratch, LDS) -- a build that spilled
+    differently once miscompiled the l_save store (csrc/Makefile)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_resources.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mcs_k_transport_plain" in r.stdout and "2 waves/SIMD" in r.stdout

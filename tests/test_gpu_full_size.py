@@ -25,7 +25,7 @@ TALLY_RTOL = 1e-11
 # 2.7e-11; bound 1e-10.  (The reference rounds its fluxes to 13 digits for the same reason, src/iter_finalize.jl:46-54.)
 LONG_SUM_RTOL = 1e-10
 LONG_SUMS = ("pxx_flux", "pxz_flux", "energy_flux", "esc_flux", "px_esc_feb", "energy_esc_feb", "esc_energy_eff", "esc_num_eff",
-             "weight_coupled", "scalars")
+             "weight_coupled", "spectra_coupled_val", "scalars")
 
 
 def _load_reducer():

@@ -487,3 +487,41 @@ def test_linearity_in_the_weights():
         b = L.view(res[1][0], name) - L.view(B, name)
         scale_ = np.max(np.abs(b)) + 1e-300
         assert np.max(np.abs(2 * a - b)) / scale_ < 1e-10, name
+
+
+def test_fp32_state_variant_statistical_agreement():
+    """BASELINE config[4]: the fp32-state kernel (state and per-step arithmetic in fp32, normalised units; tallies fp64)
+    against the fp64 path on the same seeds, 2e5 protons, whole iteration.  Histories drift apart (roundings differ), so
+    the agreement is statistical; the bound is the Monte-Carlo noise of this N (two fp64 realisations with different seeds
+    differ by as much, see tools/gpu_fp32_study.py and DESIGN.md): downstream dN/dp within 0.12 dex bin by bin over the
+    power law (30 .. 3e4 m_p c), fitted slope within 0.04 of the fp64 one and of the Keshet & Waxman index, population
+    sizes per pcut within 3 %, no zone-search failures."""
+    from test_physics import keshet_waxman_slope, dndp_slope
+    N = 200_000
+    res, probs = [], []
+    for fp32 in (False, True):
+        cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, state_fp32=fp32)
+        prob = mcs.inputs.build_problem(cfg)
+        from mcs_amd import hip_backend as hbm
+        hb = hbm.HipBackend(0); hb.create(prob)
+        res.append(mcs.driver.run(prob, hb, None, n_itrs=1)); probs.append(prob)
+        hb.destroy()
+    r64, r32 = res
+    prob = probs[0]
+    P, L = prob.params, mcs.capi.Layout(prob.params)
+    want = keshet_waxman_slope(P)
+    for zone in (P.i_shock + 3, P.i_shock + 10):
+        s64, s32 = dndp_slope(prob, L, r64.tallies_f64, zone), dndp_slope(prob, L, r32.tallies_f64, zone)
+        assert abs(s32 - s64) < 0.04 and abs(s32 - want) < 0.05, (zone, s32, s64, want)
+        a = L.view(r64.tallies_f64, "psd")[zone - 1].sum(axis=0); b = L.view(r32.tallies_f64, "psd")[zone - 1].sum(axis=0)
+        mb = prob.psd_mom_bounds
+        k = np.arange(1, P.num_psd_mom_bins)
+        pc = 10.0 ** (0.5 * (mb[k] + mb[k + 1]))
+        sel = (pc > 30.0) & (pc < 3.0e4)
+        assert np.max(np.abs(np.log10(b[k][sel] / a[k][sel]))) < 0.12, zone
+    big = [(x.n_saved, y.n_saved) for x, y in zip(r64.stats, r32.stats) if x.n_saved > N // 20]
+    assert len(big) >= 12 and max(abs(x - y) / x for x, y in big) < 0.03
+    ng, IC = P.n_grid, mcs.capi.IC
+    assert int(r32.tallies_i64[ng + IC["ZONE_FAIL"]]) == 0 and int(r32.tallies_i64[ng + IC["RETRO_CAP"]]) == 0
+    st64, st32 = r64.steps_helix + r64.steps_retro, r32.steps_helix + r32.steps_retro
+    assert abs(st32 / st64 - 1) < 0.03
