@@ -81,6 +81,7 @@ struct mcs_ctx {
   bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
   int retro_cap = MCS_RETRO_CAP;
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
+  int refill_min = 12;         // MCS_REFILL_MIN=<n> (environment) overrides: A/B measurements
   int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
   // finals
   int32_t *f_reason = nullptr, *f_helix = nullptr, *f_retro = nullptr; double *f_ptot = nullptr, *f_x = nullptr;
@@ -249,6 +250,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_REFILL_MIN"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 48) c->refill_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_DEFER_K"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 40) c->defer_k = std::atoi(e); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
@@ -576,6 +578,10 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride;
   a.retro_cap = c->retro_cap;
   a.defer_k = c->defer_k;
+  a.refill_min = c->refill_min;
+  // a wave whose live lanes all wait for company (fewer than defer_k of them) must be able to refill: with
+  // defer_k + refill_min <= 64 either defer_k lanes are live or refill_min are idle (see the deferral in transport_body)
+  if (a.defer_k > 64 - a.refill_min) a.defer_k = 64 - a.refill_min;
   a.tail_ring = c->tail_ring ? 1 : 0;
   // iseed_mod - i_prt, src/particle_loop.jl:35-40
   a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +

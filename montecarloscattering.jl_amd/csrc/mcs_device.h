@@ -51,6 +51,7 @@ struct KArgs {
   long long rep_n;           // sums are flushed into T itself); null / 0: tally into T
   double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
   int tail_ring;             // 1: sparse waves precompute the draw-dependent part of future scatters on idle lanes (MCS_TAIL_RING=0 turns it off)
+  int refill_min;            // idle lanes a wave collects before it claims new particles (MCS_REFILL_MIN = 12)
   int defer_k;               // lanes with pending rare work a wave collects before entering the rare region (MCS_DEFER_K; 1 = never wait)
   int retro_cap;             // inner steps after which one retro_time walk is ended (MCS_RETRO_CAP; tests lower it)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)

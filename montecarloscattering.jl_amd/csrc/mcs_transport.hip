@@ -1559,7 +1559,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   unsigned n_parked = 0;            // wave-uniform
   // idle lanes at which the wave has housekeeping to do: MCS_REFILL_MIN while there is unclaimed work; afterwards 1
   // while parked particles wait for a lane, else 64 (nothing left: the wave ends)
-  unsigned refill_at = MCS_REFILL_MIN;
+  const unsigned refill_min = (unsigned)__builtin_amdgcn_readfirstlane(a->refill_min);   // MCS_REFILL_MIN unless overridden (A/B runs)
+  unsigned refill_at = refill_min;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   // ---- tail ring.  After the work counter is exhausted a wave decays to a handful of live particles, and an instruction
   // costs the wave the same with 1 lane enabled as with 64.  A third of the common pass -- the Philox block of the two
@@ -1593,7 +1594,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
       if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
       // parked particles first: they run their Code Blocks together in the coming pass
-      if (n_parked > 0u && n_idle > 0 && (exhausted || n_idle >= MCS_REFILL_MIN)) {
+      if (n_parked > 0u && n_idle > 0 && (exhausted || (unsigned)n_idle >= refill_min)) {
         const unsigned take = n_parked < (unsigned)n_idle ? n_parked : (unsigned)n_idle;
         const unsigned r = below(~act_mask);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's stores to the park buffer have landed
@@ -1609,7 +1610,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       }
       // refill idle lanes (wave-aggregated claim)
       const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(active);
-      if (n_idle >= MCS_REFILL_MIN && !exhausted && idle != 0ull) {
+      if ((unsigned)n_idle >= refill_min && !exhausted && idle != 0ull) {
         const int nidle = __popcll(idle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned long long base = 0;
