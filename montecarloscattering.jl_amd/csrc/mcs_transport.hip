@@ -52,6 +52,9 @@
 #ifndef MCS_DEFER_K
 #define MCS_DEFER_K 8           // lanes with pending rare work a wave collects before it enters the rare region (see `enter` in the loop)
 #endif
+#ifndef MCS_PASSES_PER_ITER
+#define MCS_PASSES_PER_ITER 2     // common passes per trip through the loop header (see the end of the loop)
+#endif
 #ifndef MCS_MERGE_POLL_MASK
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
 #endif
@@ -1865,64 +1868,76 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
     n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));     // (unconditional: no branch in the common pass)
-    // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
-    bool got = false;
-    double rU1 = 0.0, rs = 0.0, rc = 0.0;
-    if (MCS_UNLIKELY(ring_on)) {
-      // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
-      const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
-      const unsigned L = (unsigned)__popcll(am);
-      if ((L >= 1u) & (Lh <= 32u) & (n_parked == 0u)) {
-        unsigned jj = (rng.n - rb) >> 1;
-        if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
-          // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
-          const unsigned lg = 31u - (unsigned)__builtin_clz(64u / L);
-          const unsigned D = 1u << lg;
-          const unsigned rank = below(am);
-          if (active) {
-            S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
-            S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
+    // ---- MCS_PASSES_PER_ITER common passes per trip through the loop header.  The header (housekeeping test, the want /
+    // enter logic, two branches: ~55 instructions) is a sixth of a pass; a lane that comes out of a pass with nothing
+    // pending runs the next one at once, a lane with an event or a flag sits the rest of the trip out (it is one of the
+    // few per cent of lanes that have an event in a given pass) and meets the rare region at the next header, as before.
+    bool run = !frozen;
+#pragma unroll
+    for (int rep = 0; rep < MCS_PASSES_PER_ITER; ++rep) {
+      if (rep > 0) {
+        run = run & ((((evw & 3) | p.flags) == 0)) & !h.every_pass;
+        t_clock = p.t_step;       // the previous move is now the one of the pass before, made with the current time step
+      }
+      // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
+      bool got = false;
+      double rU1 = 0.0, rs = 0.0, rc = 0.0;
+      if (MCS_UNLIKELY(ring_on)) {
+        // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+        const unsigned L = (unsigned)__popcll(am);
+        if ((L >= 1u) & (Lh <= 32u) & (n_parked == 0u)) {
+          unsigned jj = (rng.n - rb) >> 1;
+          if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
+            // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
+            const unsigned lg = 31u - (unsigned)__builtin_clz(64u / L);
+            const unsigned D = 1u << lg;
+            const unsigned rank = below(am);
+            if (active) {
+              S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
+              S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
+            }
+            const unsigned q = lane >> lg, jw = lane & (D - 1u);
+            const bool valid = q < L;
+            const unsigned qq = valid ? q : 0u;
+            const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq];
+            double eU1, es, ec;
+            scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
+            if (valid) { S_evf[wv][0][128u + lane] = eU1; S_evf[wv][1][128u + lane] = es; S_evf[wv][2][128u + lane] = ec; }   // entry q * D + jw == lane
+            if (active) { rb = rng.n; rrow = rank << lg; }
+            ringD = D;
+            jj = 0u;
           }
-          const unsigned q = lane >> lg, jw = lane & (D - 1u);
-          const bool valid = q < L;
-          const unsigned qq = valid ? q : 0u;
-          const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq];
-          double eU1, es, ec;
-          scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
-          if (valid) { S_evf[wv][0][128u + lane] = eU1; S_evf[wv][1][128u + lane] = es; S_evf[wv][2][128u + lane] = ec; }   // entry q * D + jw == lane
-          if (active) { rb = rng.n; rrow = rank << lg; }
-          ringD = D;
-          jj = 0u;
+          const unsigned idx = (rrow + jj) & 63u;
+          rU1 = S_evf[wv][0][128u + idx]; rs = S_evf[wv][1][128u + idx]; rc = S_evf[wv][2][128u + idx];
+          got = true;
+        } else {
+          rb = rng.n - 256u;            // the top of the stack may be overwritten by records now: no batch survives
         }
-        const unsigned idx = (rrow + jj) & 63u;
-        rU1 = S_evf[wv][0][128u + idx]; rs = S_evf[wv][1][128u + idx]; rc = S_evf[wv][2][128u + idx];
-        got = true;
-      } else {
-        rb = rng.n - 256u;            // the top of the stack may be overwritten by records now: no batch survives
       }
-    }
-    // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
-    if (!frozen) {
-      p.helix += 1;
-      if (!h.dont_scatter) {
-        double U1, s_ps, c_ps;
-        const uint32_t jd = rng.n;
-        rng.n = jd + 2u;
-        if (got) { U1 = rU1; s_ps = rs; c_ps = rc; }
-        else scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
-        scattering_with(p, kc, U1, s_ps, c_ps);
-      }
-      {
-        const bool ds = p.downstream;
-        const double acc_new = p.acctime + t_clock * p.z_gef;
-        p.acctime = ds ? acc_new : p.acctime;
-        p.n_ovr += (unsigned)p.ovr_inc;
-        const bool ev_time = ds && p.acctime >= p.t_ev;
-        bool x1;
-        // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
-        // due for such a lane and slow_pre ends the particle, quirk Q5)
-        const bool e1 = move_and_detect(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
-        evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
+      // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
+      if (run) {
+        p.helix += 1;
+        if (!h.dont_scatter) {
+          double U1, s_ps, c_ps;
+          const uint32_t jd = rng.n;
+          rng.n = jd + 2u;
+          if (got) { U1 = rU1; s_ps = rs; c_ps = rc; }
+          else scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
+          scattering_with(p, kc, U1, s_ps, c_ps);
+        }
+        {
+          const bool ds = p.downstream;
+          const double acc_new = p.acctime + t_clock * p.z_gef;
+          p.acctime = ds ? acc_new : p.acctime;
+          p.n_ovr += (unsigned)p.ovr_inc;
+          const bool ev_time = ds && p.acctime >= p.t_ev;
+          bool x1;
+          // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
+          // due for such a lane and slow_pre ends the particle, quirk Q5)
+          const bool e1 = move_and_detect(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
+          evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
+        }
       }
     }
   }

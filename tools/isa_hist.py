@@ -14,6 +14,7 @@ lone wave costs ~4 cycles whatever the dependency (profiles/r01_ubench_issue_lat
 5.2, RCP 16), an untaken conditional region ~36.
 """
 import collections
+import os
 import re
 import sys
 
@@ -102,10 +103,18 @@ def main():
     _, name, body = best
     hist = collections.Counter(classify(t) for t, _ in body)
     total = len(body)
+    # the loop trip holds MCS_PASSES_PER_ITER common passes behind one header (mcs_transport.hip)
+    passes = 1
+    try:
+        src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "montecarloscattering.jl_amd", "csrc", "mcs_transport.hip")).read()
+        passes = int(re.search(r"#define MCS_PASSES_PER_ITER (\d+)", src).group(1))
+    except Exception:
+        pass
     regions = [t for t, _ in body if t.startswith("s_cbranch")]
     inline = sum(1 for k in range(len(body)) if body[k][0].startswith("s_cbranch_execz") and
                  any(lab and lab[0] == body[k][0].split()[1] for _, lab in body[k:]))
-    print(f"{kernel}: particle loop header {name}; common pass = {total} instructions laid out up to the back edge")
+    print(f"{kernel}: particle loop header {name}; one trip of the loop (header + {passes} common pass{'es' if passes > 1 else ''}, nothing rare due) = "
+          f"{total} instructions laid out up to the back edge; counts below are per TRIP, the floors per PASS")
     for k in sorted(hist, key=lambda k: -hist[k]):
         print(f"  {k:20s} {hist[k]:5d}")
     valu = sum(v for k, v in hist.items() if k.startswith("valu"))
@@ -116,11 +125,11 @@ def main():
           f"({inline} in-line conditional regions, the rest guard out-of-line rare code or close the loop), LDS/VMEM {other}")
     print("branches:", "; ".join(regions))
     issue = 4.4
-    lone = (valu + salu + other) * issue + hist["branch"] * 36
-    print(f"cycle floor of one pass, lone wave : ({valu} + {salu} + {other}) x {issue} + {hist['branch']} x 36 = {lone:.0f} cycles "
+    lone = ((valu + salu + other) * issue + hist["branch"] * 36) / passes
+    print(f"cycle floor of one pass, lone wave : (({valu} + {salu} + {other}) x {issue} + {hist['branch']} x 36) / {passes} = {lone:.0f} cycles "
           f"= {lone / 2.4e3:.2f} us at 2.4 GHz  -> a 10^4-pass history (helix cap) = {lone / 2.4e3 * 1e4 / 1e3:.1f} ms")
-    two = valu * 4.0
-    print(f"VALU-issue floor (2 waves per SIMD, everything else overlapped): {valu} x 4 = {two:.0f} cycles per wave-pass "
+    two = valu * 4.0 / passes
+    print(f"VALU-issue floor (2 waves per SIMD, everything else overlapped): {valu} x 4 / {passes} = {two:.0f} cycles per wave-pass "
           f"-> {1024 * 2.4e9 / two * 64 / 1e10:.1f}e10 steps/s chip-wide with 64 live lanes; x 400 flop = "
           f"{1024 * 2.4e9 / two * 64 * 400 / 78.6e12:.2f} of the fp64 VALU peak")
 
