@@ -53,7 +53,7 @@
 #define MCS_DEFER_K 8           // lanes with pending rare work a wave collects before it enters the rare region (see `enter` in the loop)
 #endif
 #ifndef MCS_PASSES_PER_ITER
-#define MCS_PASSES_PER_ITER 2     // common passes per trip through the loop header (see the end of the loop)
+#define MCS_PASSES_PER_ITER 6     // common passes per trip through the loop header (see the end of the loop)
 #endif
 #ifndef MCS_MERGE_POLL_MASK
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
