@@ -92,8 +92,7 @@ struct mcs_ctx {
   long long rep_n = 0;                         // doubles per replica (0: no replicas)
   bool rep_dirty = false;                    // a launch may have added to the replicas since the last fold
   bool tally_replicas = true;                  // MCS_TALLY_REPLICAS_OFF=1: tally straight into T
-  double* d_park = nullptr;                    // park buffer of the transport kernel (KArgs::park)
-  bool park = true;                           // MCS_PARK=0: no parking (A/B measurements)
+  bool park = true;                           // MCS_PARK=0: lanes that need the full Code Blocks run them at once (A/B measurements)
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
   // staging for init_pop
   double* d_stage = nullptr; long long stage_cap = 0;
@@ -271,7 +270,6 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
     HIPCHK(hipMalloc((void**)&c->d_tally_rep, nrep * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));
   }
-  HIPCHK(hipMalloc((void**)&c->d_park, (size_t)MCS_PARK_WAVES * MCS_PARK_SLOTS * MCS_PARK_WORDS * sizeof(double)));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
   HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
   HIPCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
@@ -292,7 +290,7 @@ int mcs_destroy(mcs_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
-                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_park, c->d_tally_rep,
+                  c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_tally_rep,
                   c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
@@ -589,7 +587,7 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
                                      (long long)(i_pcut - 1) * c->P.n_pts_max);
   a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
   a.tail_merge = c->tail_merge ? 1 : 0;
-  a.park = c->park ? c->d_park : nullptr;
+  a.wait_full = c->park ? 1 : 0;
   a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
   if (c->debug_finals) { a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x; }
 

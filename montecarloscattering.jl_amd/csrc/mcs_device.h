@@ -49,7 +49,7 @@ struct KArgs {
   double *f_ptot, *f_x;
   double* tally_rep;         // MCS_TALLY_REPLICAS private copies of T[0 .. rep_n) for the per-event tallies (the LDS-staged
   long long rep_n;           // sums are flushed into T itself); null / 0: tally into T
-  double* park;              // park buffer: MCS_PARK_WAVES x MCS_PARK_SLOTS particle states (null: no parking)
+  int wait_full;             // 1: a lane that needs the full Code Blocks waits for company (MCS_PARK=0 turns it off: A/B runs)
   int tail_ring;             // 1: sparse waves precompute the draw-dependent part of future scatters on idle lanes (MCS_TAIL_RING=0 turns it off)
   int refill_min;            // idle lanes a wave collects before it claims new particles (MCS_REFILL_MIN = 12)
   int defer_k;               // lanes with pending rare work a wave collects before entering the rare region (MCS_DEFER_K; 1 = never wait)
@@ -64,13 +64,6 @@ struct KArgs {
 #ifndef MCS_TALLY_REPLICAS
 #define MCS_TALLY_REPLICAS 16
 #endif
-
-// particles waiting for their full Code Blocks, per wave (see the park logic of the transport kernel)
-#ifndef MCS_PARK_SLOTS
-#define MCS_PARK_SLOTS 16
-#endif
-#define MCS_PARK_WORDS 36
-#define MCS_PARK_WAVES 4096   // launches with more waves than this do not park
 
 // zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old

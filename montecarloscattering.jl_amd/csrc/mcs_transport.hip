@@ -208,7 +208,8 @@ struct Lds {};                               // an empty handle: the tables are 
 #define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
 #define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
 #define F_CM      0x200   // only cos_max is stale (fine/coarse switch in the last pass): refresh_scatter alone
-#define F_NOPARK  0x400   // just resumed from the park buffer: run the full Code Blocks now
+#define F_NOPARK  0x400   // just loaded, or released from waiting: run the full Code Blocks now
+#define F_WAIT    0x800   // needs the full Code Blocks and waits for company (see "Waiting" in transport_body): sits out the common passes
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double dphi;                   // 2pi / xn_per (particle_loop.jl:529)
@@ -1363,7 +1364,7 @@ __device__ __forceinline__ void mb_store(unsigned box, unsigned r, const Pt& p, 
 __device__ __forceinline__ void mb_load(unsigned box, unsigned r, Pt& p, Rng& rng, long long& k, int& evw, double& phi_prev) {
   state_load<MCS_MB_SLOTS, false>(&S_evf[box][0][0] + r, p, rng, k, evw, phi_prev);
 }
-static_assert(MCS_PARK_WORDS == MCS_MB_WORDS, "one state layout");
+
 
 // number of set bits of `m` below this lane (v_mbcnt: no per-lane mask register)
 __device__ __forceinline__ unsigned below(unsigned long long m) {
@@ -1547,21 +1548,19 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   if (lane == 0) { g_wave[gw__][0] = __builtin_amdgcn_s_memrealtime(); g_wave[gw__][1] = 0; }
   unsigned long long xp__ = 0, xr__ = 0, xl__ = 0, xf__ = 0;   // after exhaustion: passes, rare entries, live-lane sum, full-path lanes
 #endif
-  // Parking: a lane whose particle needs the full Code Blocks (an upward threshold, the shock, a zone with another
+  // Waiting for the full Code Blocks.  A lane whose particle needs them (an upward threshold, the shock, a zone with another
   // flow speed, ...) used to run them on the spot -- thousands of cycles for one or two lanes while the wave waits.
-  // Instead it writes the particle's state to this wave's park buffer (global memory) and goes idle; the next
-  // refill (MCS_REFILL_MIN idle lanes) takes the parked particles back first, so that they run the Code Blocks
-  // together, in one pass.  Only young particles park (a long history is what the launch waits for at the end),
-  // and nothing parks once the work counter is exhausted.  The state and the RNG stream travel with the particle.
-  // (readfirstlane: the compiler must see these as wave-uniform, or every scalar branch that depends on them
-  // turns into an exec-mask region)
-  const bool parking = __builtin_amdgcn_readfirstlane((int)(a->park != nullptr && blockDim.x == 256u && blockIdx.x * 4u + wv < (unsigned)MCS_PARK_WAVES)) != 0;
-  auto park_ptr = [&]() -> double* {      // recomputed at the (rare) uses: no registers held across the loop
-    return a->park + (size_t)(blockIdx.x * 4u + wv) * (MCS_PARK_SLOTS * MCS_PARK_WORDS);
-  };
-  unsigned n_parked = 0;            // wave-uniform
-  // idle lanes at which the wave has housekeeping to do: MCS_REFILL_MIN while there is unclaimed work; afterwards 1
-  // while parked particles wait for a lane, else 64 (nothing left: the wave ends)
+  // Instead it sets F_WAIT and sits out the common passes (nothing of its particle changes meanwhile) until the wave has
+  // refill_min lanes idle or waiting; then the idle lanes claim new particles and the waiting lanes are released
+  // (F_NOPARK), so that new and released particles run their Code Blocks together, in one pass.  Only young particles wait
+  // (a long history is what the launch waits for at the end), and nothing waits once the work counter is exhausted.
+  // (Round 1 wrote the waiting particle to a park buffer in global memory and read it back at the refill: 36 words each
+  // way and a memory latency per refill for a lane that idles just the same.)
+  // (readfirstlane: the compiler must see this as wave-uniform, or every scalar branch that depends on it turns into an
+  // exec-mask region)
+  const bool waiting_on = __builtin_amdgcn_readfirstlane((int)(a->wait_full != 0 && blockDim.x == 256u)) != 0;
+  // idle + waiting lanes at which the wave has housekeeping to do: MCS_REFILL_MIN while there is unclaimed work;
+  // afterwards 64 (nothing left: the wave ends)
   const unsigned refill_min = (unsigned)__builtin_amdgcn_readfirstlane(a->refill_min);   // MCS_REFILL_MIN unless overridden (A/B runs)
   unsigned refill_at = refill_min;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
@@ -1592,28 +1591,20 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // passes (late pcuts) a lane idles every 3-4 passes and refilling each at once cost ~25 % of the time.
     const int n_idle = 64 - __popcll(act_mask);
     unsigned Lh = 64u - (unsigned)n_idle;     // live lanes while this pass's rare region runs (housekeeping may add some)
+    const bool waitl = (p.flags & F_WAIT) != 0;                                 // (idle lanes have flags == 0)
+    const unsigned n_wait = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(waitl));
     ++mtick;
     // (bitwise | on purpose: one scalar branch, not a chain of short-circuit branches)
-    if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
+    if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle + n_wait >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
       if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
-      // parked particles first: they run their Code Blocks together in the coming pass
-      if (n_parked > 0u && n_idle > 0 && (exhausted || (unsigned)n_idle >= refill_min)) {
-        const unsigned take = n_parked < (unsigned)n_idle ? n_parked : (unsigned)n_idle;
-        const unsigned r = below(~act_mask);
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's stores to the park buffer have landed
-        if (!active && r < take) {
-          state_load<MCS_PARK_SLOTS, true>(park_ptr() + (n_parked - take + r), p, rng, k, evw, phi_prev);
-          rb = rng.n - 256u;
-          p.flags |= F_NOPARK;
-          act = -1;
-        }
-        n_parked -= take;
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        PROF_ADD(36, 1); PROF_ADD(37, take);
+      // the batch is complete: the waiting lanes run their Code Blocks in the coming pass, with the new particles
+      if (n_wait > 0u && (exhausted || (unsigned)n_idle + n_wait >= refill_min)) {
+        if (waitl) p.flags = (p.flags & ~F_WAIT) | F_NOPARK;
+        PROF_ADD(36, 1); PROF_ADD(37, n_wait);
       }
       // refill idle lanes (wave-aggregated claim)
       const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(active);
-      if ((unsigned)n_idle >= refill_min && !exhausted && idle != 0ull) {
+      if ((unsigned)n_idle + n_wait >= refill_min && !exhausted && idle != 0ull) {
         const int nidle = __popcll(idle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned long long base = 0;
@@ -1657,7 +1648,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         }
         mrole = 0; mpoll_mask = ~0u;
       };
-      if (mrole != 0 && exhausted && n_parked == 0u) {
+      if (mrole != 0 && exhausted) {
         unsigned mpartner;
         const unsigned mpair = pair_of(mpartner);
         const int nlive = __popcll(__builtin_amdgcn_ballot_w64(active));
@@ -1696,12 +1687,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           }
         }
       }
-      if (exhausted) refill_at = n_parked > 0u ? 1u : 64u;
+      if (exhausted) refill_at = 64u;
       // nothing left: the loop ends after this pass (which computes on idle lanes and stores nothing) -- no jump
       // out of the middle of the loop, which costs the common pass a branch and half a dozen register copies
       const unsigned long long am_hk = __builtin_amdgcn_ballot_w64(active);
       Lh = (unsigned)__popcll(am_hk);
-      done = (am_hk == 0ull) & exhausted & (n_parked == 0u);
+      done = (am_hk == 0ull) & exhausted;
     }
     {
       [[maybe_unused]] const int na__ = __popcll(__builtin_amdgcn_ballot_w64(active));
@@ -1717,14 +1708,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // (pending-move bits and flags in one test; bits 0-1 of evw are clear for a particle that has not moved yet)
     // (the helix cap is reported through the ev bit by the common pass, see below)
     const int wi = (((evw & 3) | p.flags) | (h.every_pass ? 1 : 0)) & act;
-    const bool want = wi != 0;
+    const bool waits = (p.flags & F_WAIT) != 0;      // (after the housekeeping, which may have released the waiting lanes)
+    const bool want = (wi != 0) & !waits;
     PROF_LANES(13, want);
 #ifdef MCS_PROF_TAIL
     const bool rare_any__ = PROF_GATE && __builtin_amdgcn_ballot_w64(want) != 0ull;
     unsigned long long tt0__ = 0;
     if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
 #endif
-    bool parked_now = false;
+    bool waits_now = false;
     // ---- deferral.  Entering the rare region costs the WAVE ~1000 cycles whatever the number of lanes in it, and in the
     // bulk of a launch some lane has a zone crossing pending in three passes out of four (2.4 lanes per entry): half of
     // all VALU issue went into the region for two or three lanes.  A lane can wait: nothing of its particle changes
@@ -1735,7 +1727,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // After the work counter is exhausted nothing waits (defer_k = 1): the launch then waits for its longest histories;
     // configurations with work in every pass (h.every_pass) never wait either.
     const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want);
-    const unsigned long long m_urgent = __builtin_amdgcn_ballot_w64((wi & (F_NEARFEB | F_NOPARK)) != 0);
+    const unsigned long long m_urgent = __builtin_amdgcn_ballot_w64(want & ((wi & (F_NEARFEB | F_NOPARK)) != 0));
     const bool enter = (m_urgent != 0ull) | ((unsigned)__popcll(m_want) >= defer_k);
     if (MCS_UNLIKELY(want & enter)) {      // (one condition, one conditional region: `enter` is wave-uniform)
       PROF_ADD(12, 1);
@@ -1769,19 +1761,14 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // most entries are plain crossings and nothing else: one scalar branch skips what follows (a dozen
       // conditional regions at ~40 cycles each even when no lane takes them)
       if (__builtin_amdgcn_ballot_w64(full || (p.flags & F_CM) != 0 || t_due || xn_due) != 0ull) {
-      if (parking && !exhausted) {
+      if (waiting_on && !exhausted) {
         if (full && moved && (p.flags & F_NOPARK) == 0 && p.helix < MCS_PARK_HELIX_MAX) {
-          const unsigned slot = n_parked + below(__builtin_amdgcn_ballot_w64(true));
-          if (slot < (unsigned)MCS_PARK_SLOTS) {
-            state_store<MCS_PARK_SLOTS>(park_ptr() + slot, p, rng, k, evw, phi_prev);
-            parked_now = true;
-            full = false;
-            act = 0; evw = 0;
-            p.flags = 0; p.helix = 0;       // an idle lane must not look as if it had work
-          }
+          p.flags |= F_WAIT;            // nothing else is touched: the lane resumes from exactly this state
+          waits_now = true;
+          full = false;
         }
       }
-      if (!full && !parked_now) {
+      if (!full && !waits_now) {
         if (p.flags & F_CM) {
           refresh_scatter(a, p, h.aa, h.aa * MP_ * CC_, h.eta);
           p.flags = 0;
@@ -1867,12 +1854,11 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #ifdef MCS_PROF_TAIL
     if (rare_any__) { const unsigned long long dt__ = __builtin_amdgcn_s_memtime() - tt0__; if (lane == 0) { atomicAdd(&S_prof[30], dt__); atomicAdd(&S_prof[31], 1ull); } }
 #endif
-    n_parked += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(parked_now));     // (unconditional: no branch in the common pass)
     // ---- MCS_PASSES_PER_ITER common passes per trip through the loop header.  The header (housekeeping test, the want /
     // enter logic, two branches: ~55 instructions) is a sixth of a pass; a lane that comes out of a pass with nothing
     // pending runs the next one at once, a lane with an event or a flag sits the rest of the trip out (it is one of the
     // few per cent of lanes that have an event in a given pass) and meets the rare region at the next header, as before.
-    bool run = !frozen;
+    bool run = !frozen & ((p.flags & F_WAIT) == 0);
 #pragma unroll
     for (int rep = 0; rep < MCS_PASSES_PER_ITER; ++rep) {
       if (rep > 0) {
@@ -1886,7 +1872,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
         const unsigned L = (unsigned)__popcll(am);
-        if ((L >= 1u) & (Lh <= 32u) & (n_parked == 0u)) {
+        if ((L >= 1u) & (Lh <= 32u)) {
           unsigned jj = (rng.n - rb) >> 1;
           if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
             // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
