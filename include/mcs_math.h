@@ -120,14 +120,17 @@ MCS_HD double cos(double x) { double s, c; sincos(x, &s, &c); return c; }
 
 /* Base.mod2pi for the bounded phase angles of the path (|x| < ~1e5). */
 MCS_HD double mod2pi(double x) {
-  double r = x;
-  if (__builtin_expect(!(r >= 0.0 && r < MCS_TWOPI), 0)) {
-    double k = __builtin_floor(x * MCS_INV_TWOPI);
-    r = fma_(-k, MCS_SC(MCS_TWOPI_DD_0), x);
-    r = fma_(-k, MCS_SC(MCS_TWOPI_DD_1), r);
-    if (r < 0.0) r += MCS_TWOPI;
-    if (r >= MCS_TWOPI) r -= MCS_TWOPI;
-  }
+  /* Straight-line on purpose: for x already in [0, 2 pi) k is 0 and both fma return x bit for bit, so the early-out of
+   * the first version ("if x is in range return it") bought nothing -- and on the GPU it was a conditional region that
+   * some lane of a wave took in every other pass (the phase leaves [0, 2 pi) once per gyration). */
+#ifdef MCS_MOD2PI_EARLY_OUT      /* A/B builds only: the first version */
+  if (__builtin_expect(x >= 0.0 && x < MCS_TWOPI, 1)) return x;
+#endif
+  const double k = __builtin_floor(x * MCS_INV_TWOPI);
+  double r = fma_(-k, MCS_SC(MCS_TWOPI_DD_0), x);
+  r = fma_(-k, MCS_SC(MCS_TWOPI_DD_1), r);
+  r = r < 0.0 ? r + MCS_TWOPI : r;
+  r = r >= MCS_TWOPI ? r - MCS_TWOPI : r;
   return r;
 }
 
