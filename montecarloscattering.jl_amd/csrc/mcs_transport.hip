@@ -225,6 +225,9 @@ struct Pt {
   // properties of zone ig3 (gamma_sf, cos theta_B, u_x, gamma_ef) and the edges of zone i_grid: read
   // from the LDS tables when the zone changes (rare code), not in every pass
   double z_gsf, z_bcos, z_ux, z_gef, z_lo, z_hi;
+  // the two numbers the common pass compares the position with (refresh_thr): every position event of
+  // move_and_detect -- zone edge, end of the grid, PRP, x_dt, fine/coarse switch -- implies x >= t_hi or x <= t_lo
+  double t_hi, t_lo;
   int flags;
   int ovr_inc;                   // 1 while downstream past the last time cut (D4 counter), else 0
   unsigned n_ovr;                // passes counted by D4, flushed when the particle ends
@@ -991,6 +994,73 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
   return ev;
 }
 
+// The position events of move_and_detect, folded into two thresholds.  Between two visits to the rare region
+// nothing that those events depend on changes except the position itself (zone edges, PRP, x_dt, gyro_rad_tot,
+// xn_per change in rare code only), so each of them is "x has come up to T" or "x has come down to T" for a T
+// known when the lane leaves the region:
+//   zone edge        fwd & x >= z_hi  |  !fwd & x < z_lo          =>  x >= z_hi | x <= z_lo
+//   grid end, PRP    x_old < T <= x: T above x now: up; else the lane must come back when x drops to T, so that
+//                    T becomes an upward threshold again (a visit with nothing due)
+//   x_dt             x > x_dt (every pass while it holds: t_hi = -inf)
+//   fine / coarse    fine: x > gyro_rad_tot; coarse: x <= gyro_rad_tot
+// The compares are non-strict, a SUPERSET of the events: the rare region re-derives the exact conditions from
+// (x, x_old) with move_and_detect's own expressions, and a lane that stopped with nothing due just carries on --
+// nothing of a particle changes while it is masked out of the common pass.  (-DMCS_CHECK_THR poisons the weight
+// of a particle whose exact test fires where the thresholds do not: tests then fail loudly.)
+__device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
+  const double x = p.x, inf = __builtin_inf();
+  double hi = p.z_hi, lo = p.z_lo;
+  const double T1 = h.x_grid_stop, T2 = p.prp, g = p.gyro_rad_tot;
+  const bool b1 = x < T1, b2 = x < T2, coarse = p.xn_per == h.xn_coarse, xg = x > g;
+  hi = (b1 & (T1 < hi)) ? T1 : hi;   lo = (!b1 & (T1 > lo)) ? T1 : lo;
+  hi = (b2 & (T2 < hi)) ? T2 : hi;   lo = (!b2 & (T2 > lo)) ? T2 : lo;
+  hi = p.x_dt < hi ? p.x_dt : hi;
+  hi = x > p.x_dt ? -inf : hi;
+  const double hi_f = xg ? -inf : (g < hi ? g : hi);       // fine steps: the switch is due once x > g
+  const double lo_c = xg ? (g > lo ? g : lo) : inf;        // coarse steps: due once x <= g
+  p.t_hi = coarse ? hi : hi_f;
+  p.t_lo = coarse ? lo_c : lo;
+}
+
+// The common pass's version of move_and_detect: same move, the position events through the two thresholds.
+// Returns the events that are not position thresholds (odd configurations); ev_cross = some threshold reached.
+__device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross) {
+  const int ig3 = p.ig3;
+  const double gsf = p.z_gsf, bcos = p.z_bcos, ux = p.z_ux;
+  p.x_old = p.x;
+  const double phi_old = p.phi;
+  phi_old_out = phi_old;
+  p.phi = mcsm::mod2pi(p.phi + p.dphi);
+  const double gm = p.gam_pf * h.m;
+  const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
+  double gyr = 0.0;
+  if (h.oblique) {
+    const double bsin = S_bsin[ig3];
+    const double g = p.gyro_rad * bsin * (mcsm::cos(p.phi) - mcsm::cos(phi_old));
+    gyr = bsin != 0.0 ? g : 0.0;
+  }
+  const double dx = gsf * (x_move * bcos - gyr + ux * p.t_step);
+  p.x = p.x_old + dx;
+  ev_cross = (p.x >= p.t_hi) | (p.x <= p.t_lo);
+#ifdef MCS_CHECK_THR
+  {
+    const bool fwd = p.x > p.x_old;
+    const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
+    const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
+    const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
+    if ((!same_zone | ev_up | ev_xn) & !ev_cross) p.weight = __builtin_nan("");
+  }
+#endif
+  bool ev = false;
+  if (h.odd_cfg) {   // wave-uniform: configurations with more per-pass conditions
+    if (h.feb_down > 0) ev |= p.x > h.feb_down;
+    if (h.dont_DSA || h.inj_frac < 1) ev |= p.x <= 0 && p.x_old > 0 && !p.inj;
+    if (h.aa < 1) ev |= p.x >= h.x_grid_stop;
+    if (h.n_xspec != 0) ev = true;
+  }
+  return ev;
+}
+
 // Everything the last move triggered (the tail of Code Block 2 and Code Block 3's all_flux /
 // downstream_test / prob_return part, particle_loop.jl:352-358, 409-499).  Returns the end code or -1.
 __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, double phi_old) {
@@ -1508,7 +1578,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   p.weight = 0; p.ptot_pf = 1; p.pb_pf = 0; p.p_perp = 1; p.gam_pf = 1; p.x = 0; p.x_old = 0; p.phi = 0; p.prp = 0; p.acctime = 0;
   p.xn_per = 1; p.dphi = 0; p.gyro_denom = 0; p.gyro_rad = 0; p.gyro_rad_tot = 0; p.gyro_period = 0; p.t_step = 0;
   p.rp_val = 1; p.cm_val = 1; p.rg_val = 1; p.x_dt = 0; p.t_ev = 0; p.flags = 0; p.ovr_inc = 0; p.n_ovr = 0u;
-  p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0;
+  p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0; p.t_hi = 0; p.t_lo = 0;
   p.i_grid = 0; p.i_grid_old = 0; p.ig3 = 0; p.helix = 0; p.tcut = 1; p.n_retro = 0; p.downstream = false; p.inj = false;
   rng.init(0ull);
   // act: -1 while the lane holds a live particle, 0 while it is idle (an all-ones / all-zeros word, so that the loop header
@@ -1643,6 +1713,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const unsigned r = below(idle_now);
         if (!active && r < cntm) {
           mb_load(mpartner, r, p, rng, k, evw, phi_prev);
+          refresh_thr(h, p);
           rb = rng.n - 256u;
           act = -1;
         }
@@ -1737,7 +1808,18 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #else
 #define TT_MARK(slot) do { } while (0)
 #endif
-      const bool ev = (evw & 1) != 0, ev_x = (evw & 2) != 0, moved = (evw & 4) != 0;
+      // (bit 1 of evw: a position threshold was reached, see refresh_thr -- what is due is derived here, with the
+      // expressions of move_and_detect; state and (x, x_old) are those the move left)
+      const bool moved = (evw & 4) != 0, thr = (evw & 2) != 0;
+      bool ev = (evw & 1) != 0, ev_x = false;
+      if (__builtin_amdgcn_ballot_w64(thr) != 0ull) {
+        const bool fwd = p.x > p.x_old;
+        const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
+        const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
+        const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
+        ev_x = thr & !same_zone;
+        ev = ev | (thr & (ev_up | ev_xn));
+      }
       [[maybe_unused]] const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
       const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
       int end = -1;
@@ -1849,6 +1931,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         TT_MARK(19);
       }
       }
+      // the position thresholds of the common pass, from the state the lane leaves the region with (a waiting lane
+      // comes back with its pending move and is refreshed then)
+      if (!waits_now) refresh_thr(h, p);
     }
     const bool frozen = want & !enter;  // waits for the region: sits out this pass
 #ifdef MCS_PROF_TAIL
@@ -1921,7 +2006,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           bool x1;
           // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
           // due for such a lane and slow_pre ends the particle, quirk Q5)
-          const bool e1 = move_and_detect(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
+          const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
           evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
         }
       }
