@@ -228,6 +228,9 @@ struct Pt {
   // the two numbers the common pass compares the position with (refresh_thr): every position event of
   // move_and_detect -- zone edge, end of the grid, PRP, x_dt, fine/coarse switch -- implies x >= t_hi or x <= t_lo
   double t_hi, t_lo;
+  // the clock of the common pass: gamma_ef of the zone while downstream, else 0 (acctime + 0 is acctime), and the time
+  // of the next clock event while downstream, else +inf -- refreshed with the thresholds
+  double c_gef, c_tev;
   int flags;
   int ovr_inc;                   // 1 while downstream past the last time cut (D4 counter), else 0
   unsigned n_ovr;                // passes counted by D4, flushed when the particle ends
@@ -1020,6 +1023,8 @@ __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
   const double lo_c = xg ? (g > lo ? g : lo) : inf;        // coarse steps: due once x <= g
   p.t_hi = coarse ? hi : hi_f;
   p.t_lo = coarse ? lo_c : lo;
+  p.c_gef = p.downstream ? p.z_gef : 0.0;
+  p.c_tev = p.downstream ? p.t_ev : inf;
 }
 
 // The common pass's version of move_and_detect: same move, the position events through the two thresholds.
@@ -1578,7 +1583,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   p.weight = 0; p.ptot_pf = 1; p.pb_pf = 0; p.p_perp = 1; p.gam_pf = 1; p.x = 0; p.x_old = 0; p.phi = 0; p.prp = 0; p.acctime = 0;
   p.xn_per = 1; p.dphi = 0; p.gyro_denom = 0; p.gyro_rad = 0; p.gyro_rad_tot = 0; p.gyro_period = 0; p.t_step = 0;
   p.rp_val = 1; p.cm_val = 1; p.rg_val = 1; p.x_dt = 0; p.t_ev = 0; p.flags = 0; p.ovr_inc = 0; p.n_ovr = 0u;
-  p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0; p.t_hi = 0; p.t_lo = 0;
+  p.z_gsf = 1; p.z_bcos = 1; p.z_ux = 0; p.z_gef = 1; p.z_lo = 0; p.z_hi = 0; p.t_hi = 0; p.t_lo = 0; p.c_gef = 0; p.c_tev = 0;
   p.i_grid = 0; p.i_grid_old = 0; p.ig3 = 0; p.helix = 0; p.tcut = 1; p.n_retro = 0; p.downstream = false; p.inj = false;
   rng.init(0ull);
   // act: -1 while the lane holds a live particle, 0 while it is idle (an all-ones / all-zeros word, so that the loop header
@@ -1987,6 +1992,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         }
       }
       // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
+      PROF_LANES(9, run & active); PROF_ADD(7, 1);
       if (run) {
         p.helix += 1;
         if (!h.dont_scatter) {
@@ -1998,11 +2004,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           scattering_with(p, kc, U1, s_ps, c_ps);
         }
         {
-          const bool ds = p.downstream;
-          const double acc_new = p.acctime + t_clock * p.z_gef;
-          p.acctime = ds ? acc_new : p.acctime;
+          // (acctime runs downstream only, particle_loop.jl:348-351: upstream c_gef is 0 and c_tev +inf, see refresh_thr)
+          p.acctime = p.acctime + t_clock * p.c_gef;
           p.n_ovr += (unsigned)p.ovr_inc;
-          const bool ev_time = ds && p.acctime >= p.t_ev;
+          const bool ev_time = p.acctime >= p.c_tev;
           bool x1;
           // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
           // due for such a lane and slow_pre ends the particle, quirk Q5)

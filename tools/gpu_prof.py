@@ -35,7 +35,7 @@ for ip in range(1, NPC + 1):
     if ip >= FIRST:
         passes = P[0]
         print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3):.3e}/s")
-        print(f"   wave passes {passes:.3e}, live lanes/pass {P[8]/passes:.1f}")
+        print(f"   wave trips {passes:.3e}, live lanes/trip {P[8]/passes:.1f}; common passes {P[7]:.3e} ({P[7]/passes:.1f} per trip), live lanes RUNNING per common pass {P[9]/max(P[7],1):.1f}")
         print(f"   rare region entered in {100*P[12]/passes:.1f} % of passes ({P[13]/max(P[12],1):.1f} lanes each); full path for {P[16]/max(P[12],1):.2f} lanes per entry")
         e = max(P[12], 1)
         print(f"   lanes per entry with: xn switch due {P[22]/e:.2f}, x>=x_up {P[23]/e:.2f}, time event {P[24]/e:.2f}, refresh flags {P[25]/e:.2f}, crossing not plain {P[26]/e:.2f}, near FEB {P[27]/e:.2f}, to be saved {P[28]/e:.2f}, new particle {P[29]/e:.2f}")
