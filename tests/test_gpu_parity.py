@@ -358,8 +358,10 @@ def test_specialised_and_general_kernel_agree(monkeypatch):
 
 
 def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
-    """K1 moves particles between lanes: a lane that needs the full Code Blocks parks its particle until the next
-    refill (MCS_PARK), and sparse waves of a block merge after the work counter is exhausted (MCS_TAIL_MERGE); the
+    """K1 reorders work: a lane that needs the full Code Blocks waits (F_WAIT) until the next refill releases the
+    batch (MCS_PARK; round 1 parked the particle in global memory), several common passes run per trip through the loop
+    header with deferred entry into the rare region, and sparse waves of a block merge -- particles move between lanes --
+    after the work counter is exhausted (MCS_TAIL_MERGE, with the tail ring MCS_TAIL_RING on its idle lanes); the
     tallies go to per-block replicas that are folded into the buffer when it is read (MCS_TALLY_REPLICAS_OFF).
     The state and the RNG stream travel with the particle: with both switched off the particles are bit-identical.
     Few blocks, so that every lane is refilled many times and both mechanisms have work."""
@@ -369,6 +371,8 @@ def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
     for on in ("1", "0"):
         monkeypatch.setenv("MCS_PARK", on)
         monkeypatch.setenv("MCS_TAIL_MERGE", on)
+        monkeypatch.setenv("MCS_TAIL_RING", on)
+        monkeypatch.setenv("MCS_DEFER_K", "8" if on == "1" else "1")
         monkeypatch.setenv("MCS_TALLY_REPLICAS_OFF", "0" if on == "1" else "1")   # 16 tally replicas folded at read time
         hb = hip_backend(prob)
         hb.set_launch(4, 256)
@@ -451,6 +455,28 @@ def test_full_iteration_binned_spectra_vs_oracle():
     assert np.array_equal(rg.tallies_i64, ro.tallies_i64)
     assert (rg.steps_helix, rg.steps_retro) == (ro.steps_helix, ro.steps_retro)
     assert [(s.n_pts_use, s.n_saved, s.i_mult) for s in rg.stats] == [(s.n_pts_use, s.n_saved, s.i_mult) for s in ro.stats]
+    assert_tallies_close(hb.layout, rg.tallies_f64, ro.tallies_f64, TALLY_RTOL)
+    hb.destroy(); ob.destroy()
+
+
+def test_config4_mixed_species_full_iteration_vs_oracle():
+    """BASELINE config[4]'s species mix on one GPU, fp64: protons + He + electrons with radiative losses and ion ->
+    electron energy transfer (the general kernel: every_pass / odd_cfg paths), a whole iteration through driver.run
+    (three species, all pcuts, tallies accumulated across species as the reference does) against the oracle.  Same
+    bar as the proton iteration: integers and per-pcut populations equal, binned spectra to 1e-11."""
+    N = 8_000
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    prob = make_problem(N, species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1),
+                                    mcs.inputs.Species(me_mp, -1.0, 1e6, 1.2)],
+                        energy_transfer_frac=0.1, radiation_losses=True)
+    ob = oracle_backend(prob, nthreads=32)
+    hb = hip_backend(prob)
+    ro = mcs.driver.run(prob, ob, n_itrs=1)
+    rg = mcs.driver.run(prob, hb, n_itrs=1)
+    assert len({s.i_ion for s in rg.stats}) == 3
+    assert np.array_equal(rg.tallies_i64, ro.tallies_i64)
+    assert (rg.steps_helix, rg.steps_retro) == (ro.steps_helix, ro.steps_retro)
+    assert [(s.i_ion, s.n_pts_use, s.n_saved, s.i_mult) for s in rg.stats] == [(s.i_ion, s.n_pts_use, s.n_saved, s.i_mult) for s in ro.stats]
     assert_tallies_close(hb.layout, rg.tallies_f64, ro.tallies_f64, TALLY_RTOL)
     hb.destroy(); ob.destroy()
 
