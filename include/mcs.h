@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCS_ABI_VERSION 2
+#define MCS_ABI_VERSION 3
 
 /* ---- physical constants (cgs).  The reference takes them from Unitful /
  * UnitfulGaussian / PhysicalConstants.CODATA2018 (src/MonteCarloScattering.jl:10-12,
@@ -228,6 +228,11 @@ int mcs_init_pop(mcs_ctx* ctx, int64_t n, int64_t j_offset, int64_t n_total,
 int mcs_init_pop_binned(mcs_ctx* ctx, int64_t n_local, int64_t j_offset, int64_t n_total, int n_bins,
                         const double* bin_ptot_pf, const double* bin_weight, const int64_t* bin_start,
                         double x_start_cm, int i_grid_start, int relativistic, int fast_push);
+/* ... for a strided shard: local particle k is global particle j_first + k * j_stride (multi-GPU: rank r of W takes
+ * j_first = r, j_stride = W, so that every rank holds the same mix of the momentum-sorted injection). */
+int mcs_init_pop_binned_strided(mcs_ctx* ctx, int64_t n_local, int64_t j_first, int64_t j_stride, int64_t n_total, int n_bins,
+                                const double* bin_ptot_pf, const double* bin_weight, const int64_t* bin_start,
+                                double x_start_cm, int i_grid_start, int relativistic, int fast_push);
 
 /* K1: the particle loop of one pcut over the resident population.
  * i_prt_offset: global index of local particle 0 minus 1 (multi-GPU shards;
@@ -237,6 +242,11 @@ int mcs_run_pcut(mcs_ctx* ctx, int i_pcut, int64_t i_prt_offset, int64_t* n_save
  * i_prt_first + k * i_prt_stride (its RNG key uses that index + 1, as i_prt in
  * src/particle_loop.jl:35-40).  mcs_run_pcut(c, i, off, ns) == mcs_run_pcut_strided(c, i, off, 1, ns). */
 int mcs_run_pcut_strided(mcs_ctx* ctx, int i_pcut, int64_t i_prt_first, int64_t i_prt_stride, int64_t* n_saved);
+/* The same with an explicit index list: local particle k carries the global 0-based index dev_gidx[k] (DEVICE
+ * memory, n = mcs_pop_size entries, owned by the caller and kept alive until the next mcs_run_pcut* or
+ * mcs_new_pcut / mcs_split_import).  This is what a multi-GPU driver needs after a LOCAL split of an interleaved
+ * shard: the children of rank r's saved particles are not an arithmetic progression of the global split. */
+int mcs_run_pcut_indexed(mcs_ctx* ctx, int i_pcut, const int64_t* dev_gidx, int64_t* n_saved);
 /* K2: pcut_finalize/new_pcut (src/cuts.jl:34-124) on device: stable compaction
  * of l_save and i_mult-fold replication with weight/i_mult. Returns new size. */
 int mcs_new_pcut(mcs_ctx* ctx, int64_t i_mult, int64_t* n_new);
@@ -253,6 +263,10 @@ int mcs_new_pcut(mcs_ctx* ctx, int64_t i_mult, int64_t* n_new);
  *     the global split population  o -> parent[o / i_mult]  with weight / i_mult  (the index arithmetic of
  *     src/cuts.jl:66-92 with a global o).  Global indices -- hence RNG keys -- are those of a one-GPU run. */
 int mcs_saved_export(mcs_ctx* ctx, int64_t cap, int64_t* dev_gidx, double* dev_f64, uint32_t* dev_meta);
+/* The index column of mcs_saved_export alone (8 B per saved particle): enough for the ranks to agree on every saved
+ * particle's position in the global order, from which a local mcs_new_pcut's children get their global indices
+ * (position * i_mult + j) without any particle leaving its GPU. */
+int mcs_saved_gidx(mcs_ctx* ctx, int64_t cap, int64_t* dev_gidx);
 int mcs_split_import(mcs_ctx* ctx, int64_t n_parents, int64_t cap, const double* dev_f64, const uint32_t* dev_meta,
                      int64_t i_mult, int64_t first, int64_t stride, int64_t n_local);
 

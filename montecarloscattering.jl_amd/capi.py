@@ -14,7 +14,7 @@ import numpy as np
 
 from .constants import PSD_MAX, NA_C
 
-MCS_ABI_VERSION = 2
+MCS_ABI_VERSION = 3
 
 c_double_p = ct.POINTER(ct.c_double)
 c_int64_p = ct.POINTER(ct.c_int64)
@@ -218,6 +218,9 @@ def load_library() -> ct.CDLL:
         "mcs_init_pop_binned": (i32, [vp, i64, i64, i64, i32, c_double_p, c_double_p, c_int64_p, dbl, i32, i32, i32]),
         "mcs_run_pcut": (i32, [vp, i32, i64, c_int64_p]),
         "mcs_run_pcut_strided": (i32, [vp, i32, i64, i64, c_int64_p]),
+        "mcs_run_pcut_indexed": (i32, [vp, i32, vp, c_int64_p]),
+        "mcs_saved_gidx": (i32, [vp, i64, vp]),
+        "mcs_init_pop_binned_strided": (i32, [vp, i64, i64, i64, i64, i32, c_double_p, c_double_p, c_int64_p, dbl, i32, i32, i32]),
         "mcs_new_pcut": (i32, [vp, i64, c_int64_p]),
         "mcs_saved_export": (i32, [vp, i64, vp, vp, vp]),
         "mcs_split_import": (i32, [vp, i64, i64, vp, vp, i64, i64, i64, i64]),
@@ -249,5 +252,5 @@ EXPORTED_SYMBOLS = [
     "mcs_pop_size", "mcs_init_pop", "mcs_init_pop_binned", "mcs_run_pcut", "mcs_new_pcut", "mcs_run_pcut_host", "mcs_read_tallies",
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
-    "mcs_run_pcut_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
+    "mcs_run_pcut_strided", "mcs_run_pcut_indexed", "mcs_saved_gidx", "mcs_init_pop_binned_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
 ]

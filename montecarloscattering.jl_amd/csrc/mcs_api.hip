@@ -23,11 +23,12 @@ hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* 
                               unsigned long long* total_dev, long long* src, hipStream_t st);
 hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st);
 hipError_t mcs_launch_saved_export(DevPop sv, const long long* src, long long n_saved, long long cap, long long first,
-                                   long long stride, long long* gidx, double* f64, uint32_t* meta, hipStream_t st);
+                                   long long stride, const long long* gin, long long* gidx, double* f64, uint32_t* meta,
+                                   hipStream_t st);
 hipError_t mcs_launch_split_import(DevPop out, const double* f64, const uint32_t* meta, long long cap, long long i_mult,
                                    long long first, long long stride, long long n_local, hipStream_t st);
 hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
-                               long long n_total, unsigned long long key, double m, double u, double x_start,
+                               long long j_stride, long long n_total, unsigned long long key, double m, double u, double x_start,
                                int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
                                int n_bins, const double* bin_ptot, const double* bin_weight, const long long* bin_start,
                                hipStream_t st);
@@ -78,6 +79,7 @@ struct mcs_ctx {
   long long n_saved_last = 0;
   long long n_run_last = 0;    // population size of the last mcs_run_pcut (the saved arrays and src[] refer to it)
   long long idx_first = 0, idx_stride = 1;   // global index of local particle k in that run: idx_first + k * idx_stride
+  const long long* idx_gidx = nullptr;       // ... or idx_gidx[k] (mcs_run_pcut_indexed; caller-owned device memory)
   bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
   int retro_cap = MCS_RETRO_CAP;
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
@@ -487,7 +489,7 @@ int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const
     HIPCHK(hipMemcpyAsync(c->d_stage, ptot_pf_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_stage + n, weight_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned long long key = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_ions + (c->i_ion - 1));
-    HIPCHK(mcs_launch_init_pop(c->cur.d, c->d_stage, c->d_stage + n, n, j_offset, n_total, key, c->m, c->h_ux[i_grid_start],
+    HIPCHK(mcs_launch_init_pop(c->cur.d, c->d_stage, c->d_stage + n, n, j_offset, 1, n_total, key, c->m, c->h_ux[i_grid_start],
                                x_start_cm, i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, 0, nullptr, nullptr, nullptr,
                                c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -499,11 +501,19 @@ int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const
 int mcs_init_pop_binned(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, int n_bins, const double* bin_ptot_pf,
                         const double* bin_weight, const int64_t* bin_start, double x_start_cm, int i_grid_start,
                         int relativistic, int fast_push) {
+  return mcs_init_pop_binned_strided(c, n, j_offset, 1, n_total, n_bins, bin_ptot_pf, bin_weight, bin_start, x_start_cm,
+                                     i_grid_start, relativistic, fast_push);
+}
+
+int mcs_init_pop_binned_strided(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t j_stride, int64_t n_total, int n_bins,
+                                const double* bin_ptot_pf, const double* bin_weight, const int64_t* bin_start, double x_start_cm,
+                                int i_grid_start, int relativistic, int fast_push) {
   HIPCHK(hipSetDevice(c->device));
   if (!c->have_grid) return fail("mcs_init_pop_binned: call mcs_set_grid first");
   if (n < 0 || n_bins < 1 || n_bins > 4096 || i_grid_start < 0 || i_grid_start > c->P.n_grid || !bin_ptot_pf || !bin_weight || !bin_start)
     return fail("mcs_init_pop_binned: bad arguments");
-  if (bin_start[0] != 0 || bin_start[n_bins] != n_total || j_offset < 0 || j_offset + n > n_total)
+  if (bin_start[0] != 0 || bin_start[n_bins] != n_total || j_offset < 0 || j_stride < 1 ||
+      (n > 0 && j_offset + (n - 1) * j_stride >= n_total))
     return fail("mcs_init_pop_binned: bin_start must run from 0 to n_total and the shard must lie inside");
   for (int b = 0; b < n_bins; ++b) {
     if (bin_start[b + 1] < bin_start[b]) return fail("mcs_init_pop_binned: bin_start must be non-decreasing");
@@ -522,7 +532,7 @@ int mcs_init_pop_binned(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total
     std::memcpy(h.data() + 2 * n_bins, bin_start, sizeof(int64_t) * (n_bins + 1));
     HIPCHK(hipMemcpyAsync(c->d_stage, h.data(), nd * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned long long key = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_ions + (c->i_ion - 1));
-    HIPCHK(mcs_launch_init_pop(c->cur.d, nullptr, nullptr, n, j_offset, n_total, key, c->m, c->h_ux[i_grid_start], x_start_cm,
+    HIPCHK(mcs_launch_init_pop(c->cur.d, nullptr, nullptr, n, j_offset, j_stride, n_total, key, c->m, c->h_ux[i_grid_start], x_start_cm,
                                i_grid_start, relativistic, fast_push, c->P.xn_per_fine, c->P.x_grid_stop, n_bins, c->d_stage,
                                c->d_stage + n_bins, (const long long*)(c->d_stage + 2 * n_bins), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));     // h goes out of scope
@@ -548,7 +558,18 @@ int mcs_run_pcut(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t* n_saved)
   return mcs_run_pcut_strided(c, i_pcut, i_prt_offset, 1, n_saved);
 }
 
+static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i_prt_stride, const int64_t* dev_gidx, int64_t* n_saved);
+
 int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i_prt_stride, int64_t* n_saved) {
+  return run_pcut_impl(c, i_pcut, i_prt_offset, i_prt_stride, nullptr, n_saved);
+}
+
+int mcs_run_pcut_indexed(mcs_ctx* c, int i_pcut, const int64_t* dev_gidx, int64_t* n_saved) {
+  if (!dev_gidx && c->n > 0) return fail("mcs_run_pcut_indexed: null index list");
+  return run_pcut_impl(c, i_pcut, 0, 1, dev_gidx, n_saved);
+}
+
+static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i_prt_stride, const int64_t* dev_gidx, int64_t* n_saved) {
   HIPCHK(hipSetDevice(c->device));
   if (i_prt_offset < 0 || i_prt_stride < 1) return fail("mcs_run_pcut: i_prt_first must be >= 0 and i_prt_stride >= 1");
   if (!c->have_grid || !c->have_cuts) return fail("mcs_run_pcut: grid/cuts not set");
@@ -573,7 +594,7 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   a.pcut = c->h_pcuts[i_pcut - 1];
   a.pcut_prev = i_pcut > 1 ? c->h_pcuts[i_pcut - 2] : 0.0;
   a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
-  a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride;
+  a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride; a.gidx = (const long long*)dev_gidx;
   a.retro_cap = c->retro_cap;
   a.defer_k = c->defer_k;
   a.refill_min = c->refill_min;
@@ -623,7 +644,7 @@ int mcs_run_pcut_strided(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_ms = ms;
   c->n_saved_last = (long long)ns[0];
-  c->n_run_last = n; c->idx_first = i_prt_offset; c->idx_stride = i_prt_stride;
+  c->n_run_last = n; c->idx_first = i_prt_offset; c->idx_stride = i_prt_stride; c->idx_gidx = (const long long*)dev_gidx;
   // every entry point that hands out l_save or the saved arrays goes through here (a spilling build of the kernel
   // once miscompiled the l_save byte store, see csrc/Makefile)
   if (ns[0] != ns[1]) return fail("mcs_run_pcut: the kernel's n_saved counter and the count of l_save flags differ");
@@ -653,9 +674,20 @@ int mcs_saved_export(mcs_ctx* c, int64_t cap, int64_t* dev_gidx, double* dev_f64
   if (c->n != c->n_run_last) return fail("mcs_saved_export: no mcs_run_pcut since the population changed");
   if (cap < c->n_saved_last) return fail("mcs_saved_export: cap < n_saved");
   if (c->n_saved_last > 0 && (!dev_gidx || !dev_f64 || !dev_meta)) return fail("mcs_saved_export: null buffer");
-  HIPCHK(mcs_launch_saved_export(c->sav.d, c->d_src, c->n_saved_last, cap, c->idx_first, c->idx_stride, (long long*)dev_gidx,
-                                 dev_f64, dev_meta, c->stream));
+  HIPCHK(mcs_launch_saved_export(c->sav.d, c->d_src, c->n_saved_last, cap, c->idx_first, c->idx_stride, c->idx_gidx,
+                                 (long long*)dev_gidx, dev_f64, dev_meta, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));      // the caller's library (RCCL on another stream) may read the buffers now
+  return 0;
+}
+
+int mcs_saved_gidx(mcs_ctx* c, int64_t cap, int64_t* dev_gidx) {
+  HIPCHK(hipSetDevice(c->device));
+  if (c->n != c->n_run_last) return fail("mcs_saved_gidx: no mcs_run_pcut since the population changed");
+  if (cap < c->n_saved_last) return fail("mcs_saved_gidx: cap < n_saved");
+  if (c->n_saved_last > 0 && !dev_gidx) return fail("mcs_saved_gidx: null buffer");
+  HIPCHK(mcs_launch_saved_export(c->sav.d, c->d_src, c->n_saved_last, cap, c->idx_first, c->idx_stride, c->idx_gidx,
+                                 (long long*)dev_gidx, nullptr, nullptr, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

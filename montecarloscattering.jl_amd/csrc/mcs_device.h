@@ -42,6 +42,7 @@ struct KArgs {
   long long n;               // local population size
   long long i_prt_offset;    // global i_prt of local particle 0, minus 1
   long long i_prt_stride;    // global i_prt of local particle k = i_prt_offset + 1 + k * i_prt_stride (1: a contiguous shard)
+  const long long* gidx;     // or, when not null: global 0-based index of local particle k (mcs_run_pcut_indexed); i_prt = gidx[k] + 1
   unsigned long long seed_base;   // iseed_mod - i_prt   (src/particle_loop.jl:35-40)
   unsigned long long* work_counter;   // next unclaimed particle
   unsigned long long* n_saved;

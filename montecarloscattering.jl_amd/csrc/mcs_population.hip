@@ -135,11 +135,13 @@ mcs_k_split(DevPop sv, DevPop out, const long long* __restrict__ src, long long 
 // all-gathers: field f of the r-th saved particle at f64[f * cap + r]; its global index first + src[r] * stride.
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_saved_export(DevPop sv, const long long* __restrict__ src, long long n_saved, long long cap, long long first,
-                   long long stride, long long* __restrict__ gidx, double* __restrict__ f64, uint32_t* __restrict__ meta) {
+                   long long stride, const long long* __restrict__ gin, long long* __restrict__ gidx, double* __restrict__ f64,
+                   uint32_t* __restrict__ meta) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_saved) return;
   const long long j = src[r];
-  gidx[r] = first + j * stride;
+  gidx[r] = gin ? gin[j] : first + j * stride;      // (gin: the index list of mcs_run_pcut_indexed)
+  if (!f64) return;                                 // mcs_saved_gidx: the indices only
   f64[r] = sv.weight[j];
   f64[cap + r] = sv.ptot_pf[j];
   f64[2 * cap + r] = sv.pb_pf[j];
@@ -172,13 +174,13 @@ mcs_k_split_import(DevPop out, const double* __restrict__ f64, const uint32_t* _
 // K3: initial population.
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_init_pop(DevPop out, const double* __restrict__ ptot_in, const double* __restrict__ weight_in, long long n,
-               long long j_offset, long long n_total, unsigned long long key, double m, double u, double x_start,
-               int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
+               long long j_offset, long long j_stride, long long n_total, unsigned long long key, double m, double u,
+               double x_start, int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
                int n_bins, const double* __restrict__ bin_ptot, const double* __restrict__ bin_weight,
                const long long* __restrict__ bin_start) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const long long j = j_offset + k;
+  const long long j = j_offset + k * j_stride;      // global 0-based index (j_stride > 1: a strided shard)
   double ptot, wgt;
   if (n_bins > 0) {
     // binned form (the momentum discretisation of set_inj_dist, initializers.jl:1251-1328): particle j
@@ -272,10 +274,11 @@ hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long lo
   return hipGetLastError();
 }
 hipError_t mcs_launch_saved_export(DevPop sv, const long long* src, long long n_saved, long long cap, long long first,
-                                   long long stride, long long* gidx, double* f64, uint32_t* meta, hipStream_t st) {
+                                   long long stride, const long long* gin, long long* gidx, double* f64, uint32_t* meta,
+                                   hipStream_t st) {
   if (n_saved > 0)
     hipLaunchKernelGGL(mcs_k_saved_export, dim3((unsigned)((n_saved + 255) / 256)), dim3(256), 0, st, sv, src, n_saved, cap,
-                       first, stride, gidx, f64, meta);
+                       first, stride, gin, gidx, f64, meta);
   return hipGetLastError();
 }
 hipError_t mcs_launch_split_import(DevPop out, const double* f64, const uint32_t* meta, long long cap, long long i_mult,
@@ -287,13 +290,13 @@ hipError_t mcs_launch_split_import(DevPop out, const double* f64, const uint32_t
 }
 
 hipError_t mcs_launch_init_pop(DevPop out, const double* ptot_in, const double* weight_in, long long n, long long j_offset,
-                               long long n_total, unsigned long long key, double m, double u, double x_start,
+                               long long j_stride, long long n_total, unsigned long long key, double m, double u, double x_start,
                                int i_grid_start, int relativistic, int fast_push, double xn_per_fine, double x_grid_stop,
                                int n_bins, const double* bin_ptot, const double* bin_weight, const long long* bin_start,
                                hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(mcs_k_init_pop, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, ptot_in, weight_in, n,
-                     j_offset, n_total, key, m, u, x_start, i_grid_start, relativistic, fast_push, xn_per_fine, x_grid_stop,
+                     j_offset, j_stride, n_total, key, m, u, x_start, i_grid_start, relativistic, fast_push, xn_per_fine, x_grid_stop,
                      n_bins, bin_ptot, bin_weight, bin_start);
   return hipGetLastError();
 }

@@ -851,7 +851,8 @@ __device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h,
   p.ig3 = p.i_grid;
   load_zone_props(p); load_zone_edges(p);
   p.helix = 0; p.n_retro = 0;
-  const unsigned long long key = a->seed_base + (unsigned long long)(a->i_prt_offset + k * a->i_prt_stride + 1);
+  const long long gi = a->gidx ? a->gidx[k] : a->i_prt_offset + k * a->i_prt_stride;     // global 0-based index
+  const unsigned long long key = a->seed_base + (unsigned long long)(gi + 1);
   rng.init(key);
 
   p.gam_pf = mcsm::hypot1(p.ptot_pf / h.mc);

@@ -6,25 +6,27 @@ here one backend call runs a whole pcut.  The population stays resident on the
 device between pcuts (K1 transport, K2 compaction+split, K3 initial fill);
 the host sees one 8-byte count per pcut.
 
-Multi-GPU (one process per GPU, torch.distributed; RCCL over xGMI when the
-backend is NCCL): particles are sharded in contiguous index ranges, the RNG key
-uses the *global* particle index so the histories do not depend on the number
-of GPUs, the per-pcut collective is an all-gather of `n_saved` (8 B per rank)
-and the per-species collective is ONE sum-all-reduce of the flat tally buffer.
-Baseline fills (1e-99 floors, analytic fast-push fluxes) live on rank 0 only so
-that the sum is the single-GPU result.
-
-`new_pcut` across ranks (src/cuts.jl:34-98 rebuilds the population from ALL saved
-particles): while many particles are saved and every rank holds its share of them
-(max/mean <= 1.1), each rank splits its own -- contiguous global index ranges, no
-data moves.  In the late pcuts a handful of particles is saved and replicated 10^5
-times; a local split would put that whole population on the one or two ranks that
-happened to hold the parents.  Then (n_saved <= `gather_max`, or the counts are
-skewed) the compacted saved particles are all-gathered (68 B each), sorted by global
-index, and rank r takes the elements r, r+W, r+2W, ... of the global split
-population: every rank gets the same number of particles (+-1) and the same mix of
-parents.  Global indices -- hence RNG keys and per-particle results -- are those of a
-one-GPU run in both cases.
+Multi-GPU (one process per GPU, torch.distributed; RCCL over xGMI when the backend is NCCL).  The RNG key of a
+particle is (iteration, species, pcut, GLOBAL particle index) whatever GPU it runs on, so the histories -- and every
+tally up to the order of the sums -- are those of a one-GPU run.  Baseline fills (1e-99 floors, analytic fast-push
+fluxes) live on rank 0 only so that the sum over ranks is the single-GPU result.
+  * The injection is dealt out like cards: rank r of W holds global particles r, r + W, r + 2W, ... -- every rank gets
+    the same mix of the momentum-sorted injection (mcs_init_pop_binned_strided).  (Round 1's contiguous ranges put all
+    the cold particles on rank 0.)
+  * Per pcut ONE small collective, all-gather(n_saved, n_local), then `new_pcut` (src/cuts.jl:34-98 rebuilds the
+    population from ALL saved particles) in one of two ways:
+      "local"   the bulk of a run (n_saved > `gather_max` and max(count) <= `skew_max` x mean): every rank replicates
+                ITS saved particles (K2 exactly as on one GPU); no particle leaves its GPU.  The ranks exchange the
+                index column only -- all-gather of the saved particles' global indices, 8 B each -- from which each
+                rank finds the position of its saved particles in the global order (one searchsorted per peer) and so
+                the global indices of their children, position * i_mult + j: the numbering of src/cuts.jl:66-92.  The
+                next pcut runs with that index list (mcs_run_pcut_indexed).
+      "gather"  few saved particles (late pcuts: a handful, each replicated 10^5 times, which a local split would
+                leave on one or two ranks) or counts that drifted apart: all-gather of the saved particles themselves
+                (mcs_saved_export, 72 B each), sorted by global index; rank r builds elements r, r + W, ... of the
+                global split (mcs_split_import) -- balanced to one particle whatever the counts were, and the shard
+                is an arithmetic progression again (mcs_run_pcut_strided).
+  * Per species ONE sum-all-reduce of the flat tally buffers (fp64 + int64), on the device under RCCL.
 """
 from __future__ import annotations
 
@@ -102,6 +104,15 @@ class Comm:
         self.dist.all_gather_into_tensor(flat, t.contiguous().view(-1))
         out = flat.view((self.world,) + tuple(t.shape))
         return torch.cat([out[r][..., :counts[r]] for r in range(self.world)], dim=-1).contiguous()
+
+    def all_gather_rows(self, t):
+        """t: [cap] on every rank -> [W, cap]."""
+        import torch
+        if not self.enabled or self.world == 1:
+            return t.view(1, -1)
+        flat = torch.zeros(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(flat, t.contiguous().view(-1))
+        return flat.view(self.world, t.numel())
 
     def all_reduce_sum_(self, tensor):
         if self.enabled:
@@ -205,15 +216,21 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     backend.write_tallies(f, i)
 
             n_total = inj.n_pts_use
-            lo, hi = shard_range(n_total, comm.rank, comm.world)
-            backend.init_pop(inj, lo, hi - lo, n_total)
-            first, stride = lo, 1       # global index of local particle k: first + k * stride
-            n_local = hi - lo
+            # the shard: global index of local particle k = first + k * stride, or gidx[k] after a local split
+            first, stride, gidx = comm.rank, comm.world, None
+            n_local = (n_total - comm.rank + comm.world - 1) // comm.world if n_total > comm.rank else 0
+            if stride == 1:
+                backend.init_pop(inj, 0, n_local, n_total)
+            else:
+                backend.init_pop(inj, first, n_local, n_total, stride)
             p_pcut_hi = inputs.pcut_hi(cfg.EN_PCUT_HI, sp.mass)
             n_use_global = n_total
             for i_pcut in range(1, n_pcuts + 1):
                 t0 = time.perf_counter()
-                n_saved_local = backend.run_pcut(i_pcut, first, stride)
+                if gidx is not None:
+                    n_saved_local = backend.run_pcut_indexed(i_pcut, gidx)
+                else:
+                    n_saved_local = backend.run_pcut(i_pcut, first, stride)
                 gathered = comm.all_gather_ints([n_saved_local, n_local])
                 counts = [g[0] for g in gathered]
                 n_use_max = max(g[1] for g in gathered)
@@ -225,8 +242,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     n_target = cfg.N_PTS_PCUT if prob.pcuts[i_pcut - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI
                     i_mult = max(n_target // n_saved, 1)         # new_pcut, src/cuts.jl:42
                 last = n_saved == 0 or i_pcut == n_pcuts
-                local_ok = stride == 1 and (not multi or (n_saved > gather_max and
-                                                          max(counts) * comm.world <= skew_max * n_saved))
+                local_ok = not multi or (n_saved > gather_max and max(counts) * comm.world <= skew_max * n_saved)
                 st = PcutStat(i_iter, i_ion, i_pcut, n_use_global, n_saved, i_mult, n_use_max,
                               "-" if last else ("local" if local_ok else "gather"), backend.last_kernel_ms(), wall)
                 stats.append(st)
@@ -237,22 +253,33 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 if n_saved == 0:
                     break
                 n_use_global = n_saved * i_mult
-                if local_ok:
-                    # every rank splits its own saved particles: contiguous global ranges, rank-major = global order
+                if not multi:
+                    backend.new_pcut(i_mult)                     # one process: the shard stays 0, 1, 2, ...
+                    n_local = n_use_global
+                elif local_ok:
+                    # every rank splits its own saved particles; the index column alone goes round
+                    g_loc = backend.saved_gidx()                                  # ascending, counts[rank] entries
+                    cap = max(max(counts), 1)
+                    pad = torch.zeros(cap, dtype=torch.int64, device=g_loc.device)
+                    pad[:g_loc.numel()] = g_loc
+                    g_all = comm.all_gather_rows(pad)                             # [W, cap]
+                    pos = torch.zeros_like(g_loc)
+                    for r in range(comm.world):                                   # saved particles of rank r below each of mine
+                        pos += torch.searchsorted(g_all[r, :counts[r]].contiguous(), g_loc)
+                    gidx = (pos[:, None] * i_mult + torch.arange(i_mult, dtype=torch.int64, device=g_loc.device)[None, :]).reshape(-1).contiguous()
                     backend.new_pcut(i_mult)
-                    first, stride = sum(counts[:comm.rank]) * i_mult, 1
                     n_local = counts[comm.rank] * i_mult
                 else:
                     # all ranks see all parents (sorted by global index); rank r builds elements r, r+W, ... of the split
-                    gidx, f64, meta = backend.export_saved(max(max(counts), 1))
-                    gidx = comm.all_gather_cols(gidx, counts)
+                    g, f64, meta = backend.export_saved(max(max(counts), 1))
+                    g = comm.all_gather_cols(g, counts)
                     f64 = comm.all_gather_cols(f64, counts)
                     meta = comm.all_gather_cols(meta, counts)
-                    order = torch.argsort(gidx, stable=True)
+                    order = torch.argsort(g, stable=True)
                     f64 = f64.index_select(1, order).contiguous()
                     meta = meta.index_select(0, order).contiguous()
-                    first, stride = comm.rank, comm.world
-                    n_local = (n_use_global - comm.rank + comm.world - 1) // comm.world
+                    first, stride, gidx = comm.rank, comm.world, None
+                    n_local = (n_use_global - comm.rank + comm.world - 1) // comm.world if n_use_global > comm.rank else 0
                     backend.import_split(f64, meta, n_saved, i_mult, first, stride, n_local)
 
             # species end: merge the partial tallies of all ranks (C1)

@@ -105,14 +105,15 @@ class HipBackend:
         self._chk(self.lib.mcs_set_fluxes(self.h, _dp(a), _dp(b), _dp(c)))
 
     # -- population
-    def init_pop(self, inj, j_offset, n_local, n_total):
-        """K3 from the binned momentum discretisation: O(bins) host work and upload, whatever N."""
+    def init_pop(self, inj, j_offset, n_local, n_total, j_stride: int = 1):
+        """K3 from the binned momentum discretisation: O(bins) host work and upload, whatever N.  Local particle k is
+        global particle j_offset + k * j_stride."""
         bp = np.ascontiguousarray(inj.bin_ptot, dtype=np.float64)
         bw = np.ascontiguousarray(inj.bin_weight, dtype=np.float64)
         bs = np.ascontiguousarray(inj.bin_start, dtype=np.int64)
-        self._chk(self.lib.mcs_init_pop_binned(self.h, n_local, j_offset, n_total, len(bp), _dp(bp), _dp(bw),
-                                               bs.ctypes.data_as(c_int64_p), inj.x_start_cm, inj.i_grid_start,
-                                               int(inj.relativistic), int(inj.fast_push)))
+        self._chk(self.lib.mcs_init_pop_binned_strided(self.h, n_local, j_offset, j_stride, n_total, len(bp), _dp(bp), _dp(bw),
+                                                       bs.ctypes.data_as(c_int64_p), inj.x_start_cm, inj.i_grid_start,
+                                                       int(inj.relativistic), int(inj.fast_push)))
 
     def init_pop_arrays(self, inj, j_offset, n_local, n_total):
         """K3 from per-particle arrays (the reference's own form of the call)."""
@@ -141,6 +142,26 @@ class HipBackend:
         self._chk(self.lib.mcs_run_pcut_strided(self.h, i_pcut, i_prt_offset, i_prt_stride, ct.byref(ns)))
         self._n_saved_last = int(ns.value)
         return int(ns.value)
+
+    def run_pcut_indexed(self, i_pcut, gidx) -> int:
+        """Local particle k has the global 0-based index gidx[k] (int64 CUDA tensor, kept alive here until the next run)."""
+        import torch
+        assert gidx.is_cuda and gidx.dtype == torch.int64 and gidx.is_contiguous() and gidx.numel() == self.pop_size()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._gidx_keep = gidx
+        ns = ct.c_int64(0)
+        self._chk(self.lib.mcs_run_pcut_indexed(self.h, i_pcut, ct.c_void_p(gidx.data_ptr()), ct.byref(ns)))
+        self._n_saved_last = int(ns.value)
+        return int(ns.value)
+
+    def saved_gidx(self):
+        """Global indices of the particles the last run_pcut* saved, in local order (int64 CUDA tensor; mcs_saved_gidx)."""
+        import torch
+        n = self._n_saved_last
+        g = torch.zeros(max(n, 1), dtype=torch.int64, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._chk(self.lib.mcs_saved_gidx(self.h, max(n, 1), ct.c_void_p(g.data_ptr())))
+        return g[:n]
 
     def set_retro_cap(self, cap: int):
         self._chk(self.lib.mcs_set_retro_cap(self.h, int(cap)))

@@ -46,13 +46,13 @@ def load(math: str = "det", capi=None):
         "orc_begin_iteration": (i32, [vp, i32]),
         "orc_begin_species": (i32, [vp, i32, i32, dbl, dbl, dbl, dbl, dbl]),
         "orc_set_fluxes": (i32, [vp, dp, dp, dp]),
-        "orc_run_pcut": (i32, [vp, i32, i64, i64, i64, soa_p, soa_p, u8p, i64p, i32]),
+        "orc_run_pcut": (i32, [vp, i32, i64, i64, i64, i64p, soa_p, soa_p, u8p, i64p, i32]),
         "orc_set_retro_cap": (i32, [vp, i64]),
         "orc_finals": (i32, [vp, i64, i32p, i32p, i32p, dp, dp]),
         "orc_read_tallies": (i32, [vp, dp, i64p]),
         "orc_write_tallies": (i32, [vp, dp, i64p]),
         "orc_new_pcut": (i64, [i64, i64, u8p, soa_p, soa_p]),
-        "orc_init_pop": (i32, [vp, i64, i64, i64, dp, dp, dbl, i32, i32, i32, soa_p]),
+        "orc_init_pop": (i32, [vp, i64, i64, i64, i64, dp, dp, dbl, i32, i32, i32, soa_p]),
         "orc_philox_block": (None, [u32p, u32p, u32p]),
         "orc_uniform": (dbl, [ct.c_uint64, ct.c_uint32, ct.c_uint64]),
         "orc_eval_fn": (i32, [i32, i64, dp, dp, dp]),
@@ -140,12 +140,13 @@ class OracleBackend:
         self._chk(self.lib.orc_set_fluxes(self.h, _dp(a), _dp(b), _dp(c)))
 
     # -- population
-    def init_pop(self, inj, j_offset, n_local, n_total):
+    def init_pop(self, inj, j_offset, n_local, n_total, j_stride=1):
         pop = self.capi.Population(n_local)
-        ptot = np.ascontiguousarray(inj.ptot_pf[j_offset:j_offset + n_local])
-        w = np.ascontiguousarray(inj.weight[j_offset:j_offset + n_local])
+        ptot = np.ascontiguousarray(inj.ptot_pf[j_offset::j_stride][:n_local])
+        w = np.ascontiguousarray(inj.weight[j_offset::j_stride][:n_local])
+        assert len(ptot) == n_local
         s = pop.soa()
-        self._chk(self.lib.orc_init_pop(self.h, n_local, j_offset, n_total, _dp(ptot), _dp(w), inj.x_start_cm,
+        self._chk(self.lib.orc_init_pop(self.h, n_local, j_offset, j_stride, n_total, _dp(ptot), _dp(w), inj.x_start_cm,
                                         inj.i_grid_start, int(inj.relativistic), int(inj.fast_push), ct.byref(s)))
         self.pop = pop
 
@@ -158,16 +159,32 @@ class OracleBackend:
     def pop_size(self):
         return self.pop.n
 
-    def run_pcut(self, i_pcut, i_prt_offset, i_prt_stride=1):
+    def run_pcut(self, i_pcut, i_prt_offset, i_prt_stride=1, gidx=None):
+        """gidx (int64 tensor / array, one global index per local particle) overrides the affine rule."""
         n = self.pop.n
-        self._idx = (int(i_prt_offset), int(i_prt_stride))
+        if gidx is not None:
+            g = np.ascontiguousarray(np.asarray(gidx, dtype=np.int64))
+            assert len(g) == n
+            self._gidx = g
+            gp = g.ctypes.data_as(ct.POINTER(ct.c_int64))
+        else:
+            self._gidx = int(i_prt_offset) + np.arange(n, dtype=np.int64) * int(i_prt_stride)
+            gp = None
         self.saved = self.capi.Population(n)
         self.l_save = np.zeros(n, dtype=np.uint8)
         ns = ct.c_int64(0)
         si, so = self.pop.soa(), self.saved.soa()
-        self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, i_prt_stride, ct.byref(si), ct.byref(so),
+        self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, i_prt_stride, gp, ct.byref(si), ct.byref(so),
                                         self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), ct.byref(ns), self.nthreads))
         return int(ns.value)
+
+    def run_pcut_indexed(self, i_pcut, gidx):
+        return self.run_pcut(i_pcut, 0, 1, gidx=gidx)
+
+    def saved_gidx(self):
+        """Global indices of the particles the last run_pcut saved, in local order (twin of mcs_saved_gidx)."""
+        import torch
+        return torch.from_numpy(self._gidx[np.flatnonzero(self.l_save)].copy())
 
     def get_saved(self):
         return self.saved, self.l_save
@@ -183,8 +200,7 @@ class OracleBackend:
         n = len(idx)
         assert cap >= n
         gidx = np.zeros(cap, np.int64); f64 = np.zeros((8, cap)); meta = np.zeros(cap, np.int32)
-        first, stride = self._idx
-        gidx[:n] = first + idx * stride
+        gidx[:n] = self._gidx[idx]
         for r, f in enumerate(F):
             f64[r, :n] = getattr(self.saved, f)[idx]
         s = self.saved

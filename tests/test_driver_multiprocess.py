@@ -54,13 +54,18 @@ def _check_equal(prob, got, ref):
     assert_tallies_close(mcs.capi.Layout(prob.params), got["f"], ref.tallies_f64, rtol=1e-12)
 
 
-@pytest.mark.parametrize("world,two", [(2, False), (3, False), (2, True)])
-def test_sharded_run_equals_single_process(tmp_path, world, two):
+@pytest.mark.parametrize("world,two,gather_max", [(2, False, 1 << 17), (3, False, 1 << 17), (2, True, 1 << 17), (3, False, 10), (2, True, 10)])
+def test_sharded_run_equals_single_process(tmp_path, world, two, gather_max):
+    """gather_max = 2^17: every pcut takes the gather split; 10: the local split with index lists (run_pcut_indexed),
+    several in a row, two iterations, two species."""
     N, npc = 150, 7
     out = str(tmp_path / f"w{world}.npz")
-    _launch(world, out, N, npc, ("2",) if two else ())
+    _launch(world, out, N, npc, (("2",) if two else ()) + (f"gather_max={gather_max}", "skew_max=3.0"))
     prob, ref = _single(N, npc, two)
-    _check_equal(prob, np.load(out), ref)
+    got = np.load(out)
+    _check_equal(prob, got, ref)
+    if gather_max == 10:
+        assert (got["split"] == "local").sum() >= 4
 
 
 @pytest.mark.parametrize("gather_max", [1 << 17, 40])
@@ -88,3 +93,30 @@ def test_late_pcuts_are_balanced_across_ranks(tmp_path, gather_max):
                 assert n_use_max[j] * world <= 1.01 * n_use[j]
         else:                                   # local split: within the accepted skew
             assert n_use_max[j] * world <= 1.1 * 1.001 * n_use[j] + world
+
+
+def test_oracle_strided_init_and_indexed_run():
+    """The oracle twins of mcs_init_pop_binned_strided / mcs_run_pcut_indexed / mcs_saved_gidx: a particle's history
+    depends on its global index only (the GPU form of this test is test_strided_init_and_indexed_run)."""
+    from conftest import make_problem, oracle_backend, start_species, assert_pop_equal
+    N, W = 600, 3
+    prob = make_problem(N)
+    ob = oracle_backend(prob)
+    inj = start_species(ob, prob)
+    N = inj.n_pts_use
+    full = ob.get_population()
+    ob.run_pcut(1, 0)
+    fin, (sav, lsave) = ob.finals(), ob.get_saved()
+    lsave = lsave.copy()
+    for r in range(W):
+        ob.init_pop(inj, r, (N - r + W - 1) // W, N, W)
+        assert_pop_equal(ob.get_population(), full.take(np.arange(r, N, W)), f"strided init, rank {r}")
+    sel = np.sort(np.random.default_rng(5).choice(N, size=177, replace=False))
+    ob.set_population(full.take(sel))
+    ns = ob.run_pcut_indexed(1, sel.astype(np.int64))
+    fa = ob.finals()
+    for k in fa:
+        assert np.array_equal(fa[k], fin[k][sel]), k
+    assert ns == int(lsave[sel].sum())
+    assert np.array_equal(ob.saved_gidx().numpy(), sel[lsave[sel] == 1])
+    ob.destroy()
