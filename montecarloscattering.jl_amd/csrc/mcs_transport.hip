@@ -58,9 +58,6 @@
 #ifndef MCS_MERGE_POLL_MASK
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
 #endif
-#ifndef MCS_PARK_HELIX_MAX
-#define MCS_PARK_HELIX_MAX 2048 // only particles younger than this many passes park
-#endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
 // calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
 #ifdef MCS_INLINE_COLD
@@ -1850,7 +1847,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // conditional regions at ~40 cycles each even when no lane takes them)
       if (__builtin_amdgcn_ballot_w64(full || (p.flags & F_CM) != 0 || t_due || xn_due) != 0ull) {
       if (waiting_on && !exhausted) {
-        if (full && moved && (p.flags & F_NOPARK) == 0 && p.helix < MCS_PARK_HELIX_MAX) {
+        // (round 1 let only particles younger than 2048 passes park -- a long history is what the launch waits for --
+        // when parking meant a round trip through global memory; waiting in the lane is faster without an age limit)
+        if (full && moved && (p.flags & F_NOPARK) == 0) {
           p.flags |= F_WAIT;            // nothing else is touched: the lane resumes from exactly this state
           waits_now = true;
           full = false;
