@@ -1845,16 +1845,16 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       TT_MARK(33);
       // most entries are plain crossings and nothing else: one scalar branch skips what follows (a dozen
       // conditional regions at ~40 cycles each even when no lane takes them)
-      if (__builtin_amdgcn_ballot_w64(full || (p.flags & F_CM) != 0 || t_due || xn_due) != 0ull) {
+      // A lane that needs the full Code Blocks waits for company (see F_WAIT): decided HERE, before the branch below, so
+      // that an entry whose only non-plain lanes are going to wait skips the rest of the region like a plain one.
+      // (round 1 let only particles younger than 2048 passes park -- a long history is what the launch waits for --
+      // when parking meant a round trip through global memory; waiting in the lane is faster without an age limit)
       if (waiting_on && !exhausted) {
-        // (round 1 let only particles younger than 2048 passes park -- a long history is what the launch waits for --
-        // when parking meant a round trip through global memory; waiting in the lane is faster without an age limit)
-        if (full && moved && (p.flags & F_NOPARK) == 0) {
-          p.flags |= F_WAIT;            // nothing else is touched: the lane resumes from exactly this state
-          waits_now = true;
-          full = false;
-        }
+        waits_now = full & moved & ((p.flags & F_NOPARK) == 0);
+        p.flags = waits_now ? (p.flags | F_WAIT) : p.flags;       // nothing else is touched: the lane resumes from exactly this state
+        full = full & !waits_now;
       }
+      if (__builtin_amdgcn_ballot_w64(full || (!waits_now && ((p.flags & F_CM) != 0 || t_due || xn_due))) != 0ull) {
       if (!full && !waits_now) {
         if (p.flags & F_CM) {
           refresh_scatter(a, p, h.aa, h.aa * MP_ * CC_, h.eta);
