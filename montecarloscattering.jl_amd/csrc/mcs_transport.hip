@@ -1838,7 +1838,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         xn_due = ev & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));
         age_out = (h.age_max > 0) & (p.acctime > h.age_max);
       }
-      bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || h.etf || h.custom_epsB ||
+      // (energy transfer, particle_loop.jl:235-249, concerns a crossing only for a particle that has not been injected
+      // yet and comes from x_old <= 0 -- slow_pre's etf_ev; `inj` as slow_post / plain_crossing leave it)
+      const bool etf_due = h.etf & ev_x & !(p.inj | (p.downstream & (p.x < 0))) & (p.x_old <= 0);
+      bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || etf_due || h.custom_epsB ||
                   (ev && (h.odd_cfg || up_due || age_out));
       TT_MARK(32);
       if (!full && ev_x) full = !plain_crossing(a, h, p, ev_pending);
