@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=60000)
     ap.add_argument("--cpu-sample-1t", type=int, default=3000, help="particles of the single-thread CPU leg (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--species-tallies", choices=("light", "full"), default="light",
+                    help="what the host fetches at every species end: the 0.8 MB it computes with (light) or the whole 61 MB buffer (full)")
     ap.add_argument("--smooth", action="store_true", help="replace the shock profile after every iteration (smooth_grid_par): config[2]'s loop")
     args = ap.parse_args()
 
@@ -157,8 +159,11 @@ def main():
     # iteration (smooth_grid_par), as in BASELINE config[2] -- the headline keeps the single unmodified shock of config[1]
     # (the stock mc_in.toml has smooth-shocks = false)
     sm = mcs.iter_finalize.SmoothingConfig(smooth_shocks=args.smooth)
+    # (--species-tallies light, the default: at a species end the host takes the 0.8 MB of the tally buffer it computes with --
+    # fluxes, escape and coupled spectra, pools, scalars, the int64 tallies; the three 20 MB histograms stay where their
+    # consumers run (K4) and are fetched once, after the last iteration.  "full" moves all 61 MB every iteration.)
     res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, on_species_end=on_species_end, on_iteration_end=on_iteration_end,
-                         smoothing=sm)
+                         smoothing=sm, species_tallies=args.species_tallies)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - marks["t0"]
@@ -200,7 +205,7 @@ def main():
                                    "45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration "
                                    "(init_pop, 45 x (transport + new_pcut), tally merge, ion_finalize consumers, iter_finalize"
                                    + (", profile smoothing" if args.smooth else "") + ")",
-                       "particles_per_gpu": args.particles, "particles_total": n_global,
+                       "particles_per_gpu": args.particles, "particles_total": n_global, "species_tallies": args.species_tallies,
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 8 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

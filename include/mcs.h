@@ -277,6 +277,11 @@ int mcs_run_pcut_host(mcs_ctx* ctx, int i_pcut, int64_t n_pts_use, int64_t i_prt
 
 /* ---- tallies ------------------------------------------------------------ */
 int mcs_read_tallies(mcs_ctx* ctx, double* host_f64 /*layout.total*/, int64_t* host_i64 /*mcs_i64_total*/);
+/* A slice of the fp64 buffer, words [first, first + count) of the layout, into host_f64[0 .. count) (+ all int64 tallies
+ * when host_i64 is not null).  The three histograms psd | therm_sf | therm_pf are 99 % of the buffer and have consumers on
+ * the device (mcs_dndp_cr, mcs_thermo_calcs); what iter_finalize needs on the host -- fluxes, escape spectra, scalars,
+ * pools (src/iter_finalize.jl:27-70) -- is the tail of the layout from esc_psd_up on: 0.8 MB instead of 61. */
+int mcs_read_tallies_part(mcs_ctx* ctx, int64_t first, int64_t count, double* host_f64, int64_t* host_i64);
 int mcs_write_tallies(mcs_ctx* ctx, const double* host_f64, const int64_t* host_i64);
 
 /* ---- consumers of the tallies, on the device-resident histograms ----

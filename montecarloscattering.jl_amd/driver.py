@@ -131,7 +131,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
-        first_iter: int = 1, iter_state=None) -> RunResult:
+        first_iter: int = 1, iter_state=None, species_tallies: str = "full") -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -144,6 +144,10 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     every iteration (smooth_grid_par) and uploaded again (mcs_set_grid / mcs_set_cuts) -- BASELINE config[2]'s loop.
     Rank 0 computes the update from the merged tallies and broadcasts the tables, so that every rank transports its
     particles through bit-identical profiles.
+    species_tallies: "full" -- every species end hands the whole tally buffer to the host (per_species, on_species_end);
+    "light" -- only the part behind the three big histograms (fluxes, escape and coupled spectra, pools, scalars: what
+    iter_finalize reads) and the int64 tallies; psd / therm_sf / therm_pf stay on the device, where their consumers run (K4),
+    and are fetched once, after the last species of the last iteration (RunResult.tallies_f64 is always complete).
     first_iter / iter_state: run iterations first_iter .. first_iter + n_itrs - 1 (the iteration number enters the
     RNG keys and indexes the per-iteration tallies), carrying the iter_finalize state of an earlier call
     (RunResult.iter_state) -- lets a caller step through the loop one iteration at a time.
@@ -292,12 +296,21 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 comm.all_reduce_sum_(tf)
                 comm.all_reduce_sum_(ti)
                 G_pool = tview(tf, "energy_transfer_pool").clone()
-                G_f, G_i = tf.cpu().numpy(), ti.cpu().numpy()
+                last_read = i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
+                if species_tallies == "light" and not last_read:
+                    o_small = L.offsets["esc_psd_up"]
+                    G_f = np.zeros(L.total)
+                    G_f[o_small:] = tf[o_small:].cpu().numpy()
+                    G_i = ti.cpu().numpy()
+                else:
+                    G_f, G_i = tf.cpu().numpy(), ti.cpu().numpy()
                 steps_seen = int(G_i[i_h] + G_i[i_r]) if is_root else 0     # rank 0 carries the merged totals on
                 if not is_root:
                     tf.zero_(); ti.zero_()
             else:
-                f, i = backend.read_tallies()
+                last_read = i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
+                light = species_tallies == "light" and not last_read and not multi and hasattr(backend, "read_tallies_light")
+                f, i = backend.read_tallies_light() if light else backend.read_tallies()
                 local_steps.append((i_iter, i_ion, int(i[i_h] + i[i_r]) - steps_seen))
                 steps_seen = int(i[i_h] + i[i_r])
                 if multi:

@@ -232,6 +232,17 @@ class HipBackend:
         self._chk(self.lib.mcs_read_tallies(self.h, _dp(f), i.ctypes.data_as(c_int64_p)))
         return f, i
 
+    def read_tallies_light(self):
+        """The same shapes as read_tallies, but only the part of the fp64 buffer behind the three big histograms is
+        fetched (fluxes, escape spectra, coupled spectra, pools, scalars: what the host's iter_finalize reads); psd /
+        therm_sf / therm_pf read as zeros -- their consumers (K4) run on the device."""
+        f = np.zeros(self.layout.total)
+        i = np.zeros(self.layout.n_i64, dtype=np.int64)
+        first = int(self.layout.offsets["esc_psd_up"])
+        tail = f[first:]
+        self._chk(self.lib.mcs_read_tallies_part(self.h, first, tail.size, _dp(tail), i.ctypes.data_as(c_int64_p)))
+        return f, i
+
     def write_tallies(self, f, i):
         f = np.ascontiguousarray(f, dtype=np.float64)
         i = np.ascontiguousarray(i, dtype=np.int64)

@@ -519,6 +519,34 @@ def test_config4_mixed_species_full_iteration_vs_oracle():
     hb.destroy(); ob.destroy()
 
 
+def test_light_tally_readback():
+    """mcs_read_tallies_part / driver.run(species_tallies="light"): at a species end the host takes only the part of the tally
+    buffer behind the three big histograms (they have consumers on the device); the final result is the complete buffer and
+    equals the one of a run that moved everything at every species end."""
+    N = 4000
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2)
+    prob = mcs.inputs.build_problem(cfg)
+    hb = hip_backend(prob)
+    seen = []
+    rl = mcs.driver.run(prob, hb, None, n_itrs=2, max_pcuts=8, species_tallies="light", finalize=True,
+                        on_species_end=lambda it, ion, f, i: seen.append((it, f.copy())))
+    f_full, i_full = hb.read_tallies()
+    f_light, i_light = hb.read_tallies_light()
+    L = hb.layout
+    o = L.offsets["esc_psd_up"]
+    assert np.array_equal(i_full, i_light) and np.array_equal(f_full[o:], f_light[o:]) and not f_light[:o].any()
+    assert f_full[:o].max() > 1e-90     # (the histograms are not empty: their floor is 1e-99)
+    hb.destroy()
+    hb = hip_backend(prob)
+    rf = mcs.driver.run(prob, hb, None, n_itrs=2, max_pcuts=8, finalize=True)
+    assert np.array_equal(rl.tallies_i64, rf.tallies_i64)
+    assert_tallies_close(L, rl.tallies_f64, rf.tallies_f64, TALLY_RTOL)
+    assert not seen[0][1][:o].any() and seen[1][1][:o].any()          # iteration 1 light, the last one complete
+    (_, fa, ia), (_, fb, ib) = rl.iter_finals[-1], rf.iter_finals[-1]
+    assert abs(fa.Gamma_downstream / fb.Gamma_downstream - 1) < 1e-10
+    hb.destroy()
+
+
 def test_linearity_in_the_weights():
     """Doubling all weights doubles every tally (power-of-two scaling is exact): 2e5 protons, 6 pcuts.
     (The full-size runs are in tests/test_gpu_full_size.py.)"""
