@@ -68,8 +68,26 @@ MCS_HD double sqrt_(double x) {
   g = __builtin_fma(d, h, g);
   return (x == 0.0 || x == __builtin_inf()) ? x : g;
 }
+/* The same for an argument known to be finite and >= 0 (1 - c^2 of a cosine, (1 - |x|) / 2 of an |x| <= 1): the
+ * reciprocal square root is taken of max(x, DBL_MIN), so that x = 0 comes out as 0 through the arithmetic itself (g = x * y
+ * = 0 and every correction term vanishes) instead of through a class test and two selects.  For every normal x the
+ * operations and their results are those of sqrt_ above. */
+MCS_HD double sqrt_nn_(double x) {
+  const double y = __builtin_amdgcn_rsq(__builtin_fmax(x, 2.2250738585072014e-308));
+  double g = x * y;
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
 #else
 MCS_HD double sqrt_(double a) { return __builtin_sqrt(a); }
+MCS_HD double sqrt_nn_(double a) { return __builtin_sqrt(a); }
 #endif
 MCS_HD double abs_(double a) { return __builtin_fabs(a); }
 MCS_HD double copysign_(double a, double b) { return __builtin_copysign(a, b); }
@@ -180,14 +198,16 @@ MCS_HD void sincos_t(double x, double* s, double* c, const HotCoef& k) {
   const double cr = fma_(z * z, pc, fma_(-0.5, z, 1.0));
   double a = (n & 1) ? cr : sr;
   double b = (n & 1) ? sr : cr;
-  *s = (n & 2) ? -a : a;
-  *c = ((n + 1) & 2) ? -b : b;
+  /* the two negations as sign-bit flips (bit 1 of the quadrant number moved to bit 63): same bits as
+   * (n & 2) ? -a : a  and  ((n + 1) & 2) ? -b : b  in sincos() above, without the compares and selects */
+  *s = from_bits_(bits_(a) ^ ((uint64_t)((uint32_t)n & 2u) << 62));
+  *c = from_bits_(bits_(b) ^ ((uint64_t)((uint32_t)(n + 1) & 2u) << 62));
 }
 MCS_HD double asin_t(double x, const HotCoef& k) {
   double ax = abs_(x);
   bool small = ax < 0.5;
   double z = small ? x * x : (1.0 - ax) * 0.5;
-  double s = small ? ax : sqrt_(z);
+  double s = small ? ax : sqrt_nn_(z);
   double p = k.A12;
   p = fma_(p, z, k.A11); p = fma_(p, z, k.A10); p = fma_(p, z, k.A9); p = fma_(p, z, k.A8); p = fma_(p, z, k.A7);
   p = fma_(p, z, k.A6); p = fma_(p, z, k.A5); p = fma_(p, z, k.A4); p = fma_(p, z, k.A3); p = fma_(p, z, k.A2);

@@ -103,7 +103,7 @@ __device__ __forceinline__ double div_r(double a, double b, double r) {
   return __builtin_fma(rem, r, q);
 }
 __device__ __forceinline__ double fdiv(double a, double b) { return div_r(a, b, rcp_refined(b)); }
-#define FSQRT(x) (mcsm::sqrt_(x))
+#define FSQRT(x) (mcsm::sqrt_nn_(x))      /* the two square roots of a scatter: arguments in [0, 1] */
 
 // ---- Philox4x32-10 ------------------------------------------------------------
 __device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -437,8 +437,7 @@ __device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, 
   const double cos_d = 1 - U1 * (1 - cos_max);
   const double sin_d = FSQRT(1 - cos_d * cos_d);
   const double cos_new = cos_old * cos_d + sin_old * sin_d * c_ps;
-  double arg = 1 - cos_new * cos_new;
-  if (arg < 0) arg = 0;
+  const double arg = __builtin_fmax(1 - cos_new * cos_new, 0.0);    // deviation D3: a rounding excess of cos_new^2 over 1 gives 0, not a DomainError
   const double sin_new = FSQRT(arg);
   p.pb_pf = p.ptot_pf * cos_new;
   p.p_perp = p.ptot_pf * sin_new;
@@ -446,7 +445,8 @@ __device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, 
   // get_sine_adjustment (scattering.jl:93-101), evaluated unconditionally and selected: for
   // sin_new == 0 the quotient is inf/NaN and is discarded.
   double sd = fdiv(s_ps * sin_d, sin_new);
-  sd = __builtin_fabs(sd) > SIN_UL ? __builtin_copysign(SIN_UL, sd) : sd;
+  // |sd| > SIN_UL ? copysign(SIN_UL, sd) : sd   as max / min (a NaN -- sin_new == 0 -- is discarded below either way)
+  sd = __builtin_fmin(__builtin_fmax(sd, -SIN_UL), SIN_UL);
   const double adj = mcsm::asin_t(sd, kc);
   const double phi_p_new = sin_new != 0 ? phi_p_old + adj : phi_p_old;
   p.phi = phi_p_new - HALFPI_;
