@@ -1952,12 +1952,18 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // pending runs the next one at once, a lane with an event or a flag sits the rest of the trip out (it is one of the
     // few per cent of lanes that have an event in a given pass) and meets the rare region at the next header, as before.
     bool run = !frozen & ((p.flags & F_WAIT) == 0);
+    // (who goes on after a pass is lane-mask arithmetic on the pass's own compare results -- scalar instructions, which
+    // issue beside the other wave's vector ones -- instead of a round trip through the bits of evw: flags do not change
+    // in a pass)
+    const bool may_go_on = (p.flags == 0) & !h.every_pass;
+    bool stopped = false;
 #pragma unroll
     for (int rep = 0; rep < MCS_PASSES_PER_ITER; ++rep) {
       if (rep > 0) {
-        run = run & ((((evw & 3) | p.flags) == 0)) & !h.every_pass;
+        run = run & may_go_on & !stopped;
         t_clock = p.t_step;       // the previous move is now the one of the pass before, made with the current time step
       }
+      stopped = false;
       // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
       bool got = false;
       double rU1 = 0.0, rs = 0.0, rc = 0.0;
@@ -2016,6 +2022,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           // due for such a lane and slow_pre ends the particle, quirk Q5)
           const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
           evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
+          stopped = e1 | x1;
         }
       }
     }
