@@ -429,13 +429,17 @@ __device__ __forceinline__ void scatter_draws(uint32_t k0, uint32_t k1, uint32_t
   mcsm::sincos_t(phi_scat, &s_ps, &c_ps, kc);
 }
 
-// src/scattering.jl:61-101: the per-step part (new pitch, phase adjustment) given the draw-dependent values; straight-line code
-__device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, double U1, double s_ps, double c_ps) {
-  const double cos_max = p.cm_val;
+// src/scattering.jl:61-101: the per-step part (new pitch, phase adjustment) given the values that depend on the draws and on
+// cos_max alone -- cos and sin of the deflection, cos of the azimuth, sin(azimuth) * sin(deflection): scatter_cone() --;
+// straight-line code
+__device__ __forceinline__ void scatter_cone(double U1, double s_ps, double omc, double& cos_d, double& sin_d, double& ssd) {
+  cos_d = 1 - U1 * omc;                                              // == 1 - U1 * (1 - cos_max), scattering.jl:68
+  sin_d = FSQRT(1 - cos_d * cos_d);
+  ssd = s_ps * sin_d;                                                // the numerator of get_sine_adjustment (scattering.jl:94)
+}
+__device__ __forceinline__ void scattering_rest(Pt& p, const mcsm::HotCoef& kc, double cos_d, double sin_d, double c_ps, double ssd) {
   const double cos_old = div_r(p.pb_pf, p.ptot_pf, p.rp_val);      // == pb_pf / ptot_pf
   const double sin_old = div_r(p.p_perp, p.ptot_pf, p.rp_val);     // == p_perp / ptot_pf
-  const double cos_d = 1 - U1 * (1 - cos_max);
-  const double sin_d = FSQRT(1 - cos_d * cos_d);
   const double cos_new = cos_old * cos_d + sin_old * sin_d * c_ps;
   const double arg = __builtin_fmax(1 - cos_new * cos_new, 0.0);    // deviation D3: a rounding excess of cos_new^2 over 1 gives 0, not a DomainError
   const double sin_new = FSQRT(arg);
@@ -444,12 +448,17 @@ __device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, 
   const double phi_p_old = p.phi + HALFPI_;
   // get_sine_adjustment (scattering.jl:93-101), evaluated unconditionally and selected: for
   // sin_new == 0 the quotient is inf/NaN and is discarded.
-  double sd = fdiv(s_ps * sin_d, sin_new);
+  double sd = fdiv(ssd, sin_new);
   // |sd| > SIN_UL ? copysign(SIN_UL, sd) : sd   as max / min (a NaN -- sin_new == 0 -- is discarded below either way)
   sd = __builtin_fmin(__builtin_fmax(sd, -SIN_UL), SIN_UL);
   const double adj = mcsm::asin_t(sd, kc);
   const double phi_p_new = sin_new != 0 ? phi_p_old + adj : phi_p_old;
   p.phi = phi_p_new - HALFPI_;
+}
+__device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, double U1, double s_ps, double c_ps) {
+  double cos_d, sin_d, ssd;
+  scatter_cone(U1, s_ps, 1 - p.cm_val, cos_d, sin_d, ssd);
+  scattering_rest(p, kc, cos_d, sin_d, c_ps, ssd);
 }
 // the two draws of a scatter are indices n, n+1 = one Philox block
 __device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef& kc) {
@@ -1638,14 +1647,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   unsigned refill_at = refill_min;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   // ---- tail ring.  After the work counter is exhausted a wave decays to a handful of live particles, and an instruction
-  // costs the wave the same with 1 lane enabled as with 64.  A third of the common pass -- the Philox block of the two
-  // draws, their conversion, sin / cos of the scattering azimuth: scatter_draws() -- depends on nothing but the
-  // particle's random stream (key, draw index), so the idle lanes compute it AHEAD: with L <= 32 live lanes, lane w
-  // evaluates block j = w mod D of the next D = 2^floor(log2(64 / L)) scatters of the (w / D)-th live particle, all in
-  // one pass of those ~115 instructions; the results sit in the free top of the wave's record stack (entries 128..191:
-  // at most 63 + 2 L <= 127 records are pending) and the live lane reads its three doubles back in each of the next D
+  // costs the wave the same with 1 lane enabled as with 64.  Half of the common pass -- the Philox block of the two
+  // draws, their conversion, sin / cos of the scattering azimuth: scatter_draws(), and cos / sin of the deflection:
+  // scatter_cone() -- depends on nothing but the particle's random stream (key, draw index) and its cos_max, which
+  // changes in rare code only, so the idle lanes compute it AHEAD: with L <= 32 live lanes, lane w
+  // evaluates block j = w mod D of the next D = floor(64 / L) scatters of the (w / D)-th live particle, all in
+  // one pass of those ~130 instructions; the results sit in the free top of the wave's record stack (entries 128..191:
+  // at most 63 + 2 L <= 127 records are pending) and the live lane reads its four doubles back in each of the next D
   // passes.  An entry is addressed by draw index (entry j <-> index rb + 2j), so draws taken in rare code in between
-  // (prob_return, the retro walk: whole blocks) just skip entries; a lane whose particle changes invalidates its batch.
+  // (prob_return, the retro walk: whole blocks) just skip entries; a lane whose particle or cos_max changes invalidates its batch.
   // Same functions, same bits: per-particle results are unchanged.
   bool ring_on = false;             // wave-uniform: the work counter is exhausted (and KArgs::tail_ring)
   unsigned rb = 0u - 256u;          // draw index of entry 0 of this lane's batch; (rng.n - rb) / 2 >= ringD: no entry
@@ -1813,6 +1823,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
 #endif
       // (bit 1 of evw: a position threshold was reached, see refresh_thr -- what is due is derived here, with the
       // expressions of move_and_detect; state and (x, x_old) are those the move left)
+      const double cm_in = p.cm_val;          // (a batch of the tail ring is built on it: compared at the end of the region)
       const bool moved = (evw & 4) != 0, thr = (evw & 2) != 0;
       bool ev = (evw & 1) != 0, ev_x = false;
       if (__builtin_amdgcn_ballot_w64(thr) != 0ull) {
@@ -1942,6 +1953,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // the position thresholds of the common pass, from the state the lane leaves the region with (a waiting lane
       // comes back with its pending move and is refreshed then)
       if (!waits_now) refresh_thr(h, p);
+      if (MCS_UNLIKELY(ring_on)) rb = (p.cm_val != cm_in) ? rng.n - 256u : rb;      // the cone changed: this lane's batch is void
     }
     const bool frozen = want & !enter;  // waits for the region: sits out this pass
 #ifdef MCS_PROF_TAIL
@@ -1966,7 +1978,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       stopped = false;
       // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
       bool got = false;
-      double rU1 = 0.0, rs = 0.0, rc = 0.0;
+      double r_cd = 0.0, r_sd = 0.0, r_c = 0.0, r_ssd = 0.0;      // cos / sin of the deflection, cos of the azimuth, sin(azimuth) * sin(deflection)
       if (MCS_UNLIKELY(ring_on)) {
         // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
@@ -1975,26 +1987,33 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           unsigned jj = (rng.n - rb) >> 1;
           if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
             // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
-            const unsigned lg = 31u - (unsigned)__builtin_clz(64u / L);
-            const unsigned D = 1u << lg;
+            // D = floor(64 / L) draws ahead per live particle (any D, not just powers of two: L = 10 gets 6, not 4);
+            // lane -> (particle q, draw jw) by a multiply and a shift: floor(lane / D) == (lane * M) >> 16 with
+            // M = floor(65536 / D) + 1 for every lane < 64 and D <= 64
+            const unsigned D = 64u / L;
+            const unsigned M = 65536u / D + 1u;
             const unsigned rank = below(am);
             if (active) {
               S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
               S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
+              S_evf[wv][5][128u + rank] = 1 - p.cm_val;      // the owner's 1 - cos_max: the cone of the deflection is part of the batch
             }
-            const unsigned q = lane >> lg, jw = lane & (D - 1u);
+            const unsigned q = (lane * M) >> 16, jw = lane - q * D;
             const bool valid = q < L;
             const unsigned qq = valid ? q : 0u;
-            const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq];
-            double eU1, es, ec;
+            const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq], womc = S_evf[wv][5][128u + qq];
+            double eU1, es, ec, ecd, esd, essd;
             scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
-            if (valid) { S_evf[wv][0][128u + lane] = eU1; S_evf[wv][1][128u + lane] = es; S_evf[wv][2][128u + lane] = ec; }   // entry q * D + jw == lane
-            if (active) { rb = rng.n; rrow = rank << lg; }
+            scatter_cone(eU1, es, womc, ecd, esd, essd);
+            if (valid) {       // entry q * D + jw == lane
+              S_evf[wv][0][128u + lane] = ecd; S_evf[wv][1][128u + lane] = esd; S_evf[wv][2][128u + lane] = ec; S_evf[wv][6][128u + lane] = essd;
+            }
+            if (active) { rb = rng.n; rrow = rank * D; }
             ringD = D;
             jj = 0u;
           }
           const unsigned idx = (rrow + jj) & 63u;
-          rU1 = S_evf[wv][0][128u + idx]; rs = S_evf[wv][1][128u + idx]; rc = S_evf[wv][2][128u + idx];
+          r_cd = S_evf[wv][0][128u + idx]; r_sd = S_evf[wv][1][128u + idx]; r_c = S_evf[wv][2][128u + idx]; r_ssd = S_evf[wv][6][128u + idx];
           got = true;
         } else {
           rb = rng.n - 256u;            // the top of the stack may be overwritten by records now: no batch survives
@@ -2005,12 +2024,16 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       if (run) {
         p.helix += 1;
         if (!h.dont_scatter) {
-          double U1, s_ps, c_ps;
+          double cos_d, sin_d, c_ps, ssd;
           const uint32_t jd = rng.n;
           rng.n = jd + 2u;
-          if (got) { U1 = rU1; s_ps = rs; c_ps = rc; }
-          else scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
-          scattering_with(p, kc, U1, s_ps, c_ps);
+          if (got) { cos_d = r_cd; sin_d = r_sd; c_ps = r_c; ssd = r_ssd; }
+          else {
+            double U1, s_ps;
+            scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
+            scatter_cone(U1, s_ps, 1 - p.cm_val, cos_d, sin_d, ssd);
+          }
+          scattering_rest(p, kc, cos_d, sin_d, c_ps, ssd);
         }
         {
           // (acctime runs downstream only, particle_loop.jl:348-351: upstream c_gef is 0 and c_tev +inf, see refresh_thr)

@@ -15,8 +15,8 @@ DEFAULT = os.path.join(ROOT, "montecarloscattering.jl_amd", "csrc", "mcs_transpo
 
 # kernel -> (max VGPRs, max VGPR spills, max scratch bytes/lane, required occupancy [waves/SIMD], max LDS bytes/block)
 LIMITS = {
-    "mcs_k_transport_plain": dict(vgprs=256, vgpr_spill=40, scratch=80, occupancy=2, lds=81920),
-    "mcs_k_transport": dict(vgprs=256, vgpr_spill=40, scratch=80, occupancy=2, lds=81920),
+    "mcs_k_transport_plain": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
+    "mcs_k_transport": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
     "mcs_k_transport_f32": dict(vgprs=128, vgpr_spill=0, scratch=256, occupancy=4, lds=40960),
 }
 
