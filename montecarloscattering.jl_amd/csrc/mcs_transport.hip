@@ -1978,7 +1978,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       stopped = false;
       // ---- tail ring (see above): the draw-dependent part of this pass's scatter, from the ring if the wave has one
       bool got = false;
-      double r_cd = 0.0, r_sd = 0.0, r_c = 0.0, r_ssd = 0.0;      // cos / sin of the deflection, cos of the azimuth, sin(azimuth) * sin(deflection)
+      unsigned ridx = 0u;          // the ring entry this pass takes its four values from (read where they are used: nothing to merge on the bulk path)
       if (MCS_UNLIKELY(ring_on)) {
         // (Lh, not L: the records pushed in this pass's rare region came from up to Lh lanes -- at most 63 + 2 Lh are pending)
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
@@ -2012,8 +2012,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             ringD = D;
             jj = 0u;
           }
-          const unsigned idx = (rrow + jj) & 63u;
-          r_cd = S_evf[wv][0][128u + idx]; r_sd = S_evf[wv][1][128u + idx]; r_c = S_evf[wv][2][128u + idx]; r_ssd = S_evf[wv][6][128u + idx];
+          ridx = (rrow + jj) & 63u;
           got = true;
         } else {
           rb = rng.n - 256u;            // the top of the stack may be overwritten by records now: no batch survives
@@ -2027,7 +2026,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           double cos_d, sin_d, c_ps, ssd;
           const uint32_t jd = rng.n;
           rng.n = jd + 2u;
-          if (got) { cos_d = r_cd; sin_d = r_sd; c_ps = r_c; ssd = r_ssd; }
+          if (got) { cos_d = S_evf[wv][0][128u + ridx]; sin_d = S_evf[wv][1][128u + ridx]; c_ps = S_evf[wv][2][128u + ridx]; ssd = S_evf[wv][6][128u + ridx]; }
           else {
             double U1, s_ps;
             scatter_draws(rng.k0, rng.k1, jd >> 1, kc, U1, s_ps, c_ps);
