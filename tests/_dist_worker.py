@@ -19,7 +19,7 @@ def main():
     # "oracle": CPU oracle over gloo; "hip-gloo": HIP backend, all ranks on GPU 0, CUDA tensors over
     # gloo (rehearses the device-side merge on a one-GPU box); "hip": one GPU per rank over RCCL
     dist.init_process_group("nccl" if backend_kind == "hip" else "gloo", rank=rank, world_size=world)
-    # further arguments: "2" (two species) and key=value options: itrs=, gather_max=, skew_max=
+    # further arguments: "2" (two species) and key=value options: itrs=, gather_max=, skew_max=, species_tallies=, finalize=
     two_species = "2" in sys.argv[5:]
     opt = dict(a.split("=", 1) for a in sys.argv[5:] if "=" in a)
     n_itrs = int(opt.get("itrs", 2))
@@ -41,7 +41,8 @@ def main():
     be.create(prob)
     comm = mcs.driver.Comm(True, dev)
     res = mcs.driver.run(prob, be, comm, n_itrs=n_itrs, max_pcuts=npc, gather_max=int(opt.get("gather_max", 1 << 17)),
-                         skew_max=float(opt.get("skew_max", 1.1)))
+                         skew_max=float(opt.get("skew_max", 1.1)), species_tallies=opt.get("species_tallies", "full"),
+                         finalize=opt.get("finalize", "0") == "1")
     if rank == 0:
         np.savez(out, f=res.tallies_f64, i=res.tallies_i64,
                  stats=np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in res.stats]),

@@ -239,6 +239,28 @@ def test_rccl_world1_rehearsal():
     hb.destroy()
 
 
+def test_two_ranks_light_tallies_and_finalize():
+    """What bench.py runs with N > 1: two ranks (gloo, one device), two species, the light tally hand-over at species ends
+    (only the part behind the three histograms crosses to the host until the last iteration) and ion_finalize /
+    iter_finalize on rank 0 -- against the plain single-process run."""
+    import os, tempfile
+    N, npc = 3000, 9
+    out = os.path.join(tempfile.mkdtemp(), "w2l.npz")
+    _run_worker(2, [out, "hip-gloo", str(N), str(npc), "2", "gather_max=800", "species_tallies=light", "finalize=1"])
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2,
+                            species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)],
+                            energy_transfer_frac=0.1)
+    prob = mcs.inputs.build_problem(cfg)
+    hb = hip_backend(prob)
+    ref = mcs.driver.run(prob, hb, None, n_itrs=2, max_pcuts=npc, finalize=True)
+    got = np.load(out)
+    stats_ref = np.array([[s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult] for s in ref.stats])
+    assert np.array_equal(got["stats"], stats_ref)
+    assert np.array_equal(got["i"], ref.tallies_i64)
+    assert_tallies_close(mcs.capi.Layout(prob.params), got["f"], ref.tallies_f64, 1e-10)
+    hb.destroy()
+
+
 def test_protons_ragged_population():
     """N not a multiple of the wavefront size; 12 pcuts of the stock ladder."""
     N = 3001
