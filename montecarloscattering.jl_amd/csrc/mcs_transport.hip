@@ -1826,13 +1826,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       const double cm_in = p.cm_val;          // (a batch of the tail ring is built on it: compared at the end of the region)
       const bool moved = (evw & 4) != 0, thr = (evw & 2) != 0;
       bool ev = (evw & 1) != 0, ev_x = false;
+      bool up_due = false, xn_due = false;    // the upward thresholds / the fine-coarse switch of move_and_detect: they imply `thr`
       if (__builtin_amdgcn_ballot_w64(thr) != 0ull) {
         const bool fwd = p.x > p.x_old;
         const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
         const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
         const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
         ev_x = thr & !same_zone;
-        ev = ev | (thr & (ev_up | ev_xn));
+        up_due = thr & ev_up; xn_due = thr & ev_xn;
+        ev = ev | up_due | xn_due;
       }
       [[maybe_unused]] const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
       const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
@@ -1842,11 +1844,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // light path: those leave every other derived quantity as it is (see slow_post / slow_pre, whose remaining
       // statements are no-ops then); anything else -- flags, an upward threshold, the age limit, odd
       // configurations -- goes through the full Code Blocks.
-      bool up_due = false, t_due = false, xn_due = false, age_out = false;
+      bool t_due = false, age_out = false;
       if (__builtin_amdgcn_ballot_w64(ev) != 0ull) {      // most entries are zone crossings only
-        up_due = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
         t_due = ev & p.downstream & (p.acctime >= p.t_ev);
-        xn_due = ev & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));
         age_out = (h.age_max > 0) & (p.acctime > h.age_max);
       }
       // (energy transfer, particle_loop.jl:235-249, concerns a crossing only for a particle that has not been injected
