@@ -131,7 +131,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
-        first_iter: int = 1, iter_state=None, species_tallies: str = "full") -> RunResult:
+        first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -147,7 +147,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     species_tallies: "full" -- every species end hands the whole tally buffer to the host (per_species, on_species_end);
     "light" -- only the part behind the three big histograms (fluxes, escape and coupled spectra, pools, scalars: what
     iter_finalize reads) and the int64 tallies; psd / therm_sf / therm_pf stay on the device, where their consumers run (K4),
-    and are fetched once, after the last species of the last iteration (RunResult.tallies_f64 is always complete).
+    and are fetched once, after the last species of the last iteration (RunResult.tallies_f64 is then complete; with
+    final_full_read = False not even then -- run_overlapped fetches every context's buffer once, at the very end).
     first_iter / iter_state: run iterations first_iter .. first_iter + n_itrs - 1 (the iteration number enters the
     RNG keys and indexes the per-iteration tallies), carrying the iter_finalize state of an earlier call
     (RunResult.iter_state) -- lets a caller step through the loop one iteration at a time.
@@ -296,7 +297,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 comm.all_reduce_sum_(tf)
                 comm.all_reduce_sum_(ti)
                 G_pool = tview(tf, "energy_transfer_pool").clone()
-                last_read = i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
+                last_read = final_full_read and i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
                 if species_tallies == "light" and not last_read:
                     o_small = L.offsets["esc_psd_up"]
                     G_f = np.zeros(L.total)
@@ -308,7 +309,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 if not is_root:
                     tf.zero_(); ti.zero_()
             else:
-                last_read = i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
+                last_read = final_full_read and i_iter == first_iter + n_itrs - 1 and i_ion == len(cfg.species)
                 light = species_tallies == "light" and not last_read and not multi and hasattr(backend, "read_tallies_light")
                 f, i = backend.read_tallies_light() if light else backend.read_tallies()
                 local_steps.append((i_iter, i_ion, int(i[i_h] + i[i_r]) - steps_seen))
@@ -362,3 +363,75 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     return RunResult(G_f, G_i, per_species, stats,
                      int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]), iter_finals,
                      it_state if finalize else None, local_steps)
+
+
+# The never-reset tallies of the reference (esc_flux, esc_*_eff, spectra_coupled, spectra_sf / _pf accumulate over
+# the iterations of a run; px_esc_feb / energy_esc_feb are indexed by iteration): sums over iterations, hence over contexts.
+ACCUMULATED_OVER_ITERATIONS = ("esc_flux", "px_esc_feb", "energy_esc_feb", "esc_energy_eff", "esc_num_eff", "spectra_coupled",
+                               "spectra_sf", "spectra_pf")
+
+
+def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pcuts: Optional[int] = None,
+                   on_iteration_end: Optional[Callable] = None, first_iter: int = 1) -> RunResult:
+    """The iterations of a run with a FIXED shock profile (smooth-shocks = false -- the stock mc_in.toml, BASELINE
+    config[1]) are independent Monte-Carlo realisations: nothing an iteration computes enters the next one's transport
+    (src/main_loops.jl:52-121: every tally the transport reads is reset at the top; the RNG keys carry i_iter).  Their
+    launches can therefore share the GPU: len(backends) iterations are in flight at a time, each on its own context and
+    HIP stream, driven by its own host thread; while one iteration's launch waits for its longest histories (the per-pcut
+    tail, 40 % of an iteration at 10^6 particles) the blocks of the other's become resident on the CUs it has freed.
+    Per-iteration results are those of run(): same keys, same populations; iter_finalize runs on the host in iteration
+    order.  The tallies the reference never resets are sums over iterations and are merged over the contexts at the end.
+    Single process only (no communicator): collectives issued from two threads would need an order."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from . import consumers, iter_finalize as itf
+    cfg, P = prob.cfg, prob.params
+    n_itrs = n_itrs if n_itrs is not None else cfg.num_iterations
+    K = len(backends)
+    assert K >= 1
+    L = backends[0].layout
+    sm = itf.SmoothingConfig(smooth_shocks=False)
+    st = itf.IterState.create(prob, sm, P.n_itrs)
+    locks = [threading.Lock() for _ in backends]
+
+    def one(i_iter):
+        k = (i_iter - first_iter) % K
+        with locks[k]:                       # a context carries one iteration at a time
+            be = backends[k]
+            res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False)
+            ion_fin = consumers.ion_finalize(prob, be, len(cfg.species))     # K4, before the context is reused
+        return k, res, ion_fin
+
+    stats, per_species, iter_finals, local_steps = [], [], [], []
+    last = {}                                 # context -> its latest result (running totals of the never-reset tallies)
+    from .capi import IC
+    ng = P.n_grid
+    total = []                                # the step counters are running totals of a context: where each one starts
+    for be in backends:
+        _, i0 = be.read_tallies_light() if hasattr(be, "read_tallies_light") else be.read_tallies()
+        total.append(int(i0[ng + IC["STEPS_HELIX"]] + i0[ng + IC["STEPS_RETRO"]]))
+    with ThreadPoolExecutor(max_workers=K) as pool:
+        futs = [pool.submit(one, i) for i in range(first_iter, first_iter + n_itrs)]
+        for i_iter, fu in zip(range(first_iter, first_iter + n_itrs), futs):      # consumed in iteration order
+            k, res, ion_fin = fu.result()
+            fin = itf.iter_finalize(prob, st, sm, i_iter, res.tallies_f64, L, ion_fin.P_psd_par, ion_fin.P_psd_perp,
+                                    ion_fin.energy_density_psd)
+            local_steps.append((i_iter, len(cfg.species), res.steps_helix + res.steps_retro - total[k]))
+            total[k] = res.steps_helix + res.steps_retro
+            last[k] = res
+            stats.extend(res.stats); per_species.extend(res.per_species); iter_finals.append((i_iter, fin, ion_fin))
+            if on_iteration_end is not None:
+                on_iteration_end(i_iter)
+    # the state after the last iteration: its context's buffer, with the never-reset tallies summed over the contexts
+    k_last = (n_itrs - 1) % K
+    f, i64 = backends[k_last].read_tallies()              # the only time the three histograms cross to the host
+    for k in last:
+        if k == k_last:
+            continue
+        fk, ik = (backends[k].read_tallies_light() if hasattr(backends[k], "read_tallies_light") else backends[k].read_tallies())
+        for name in ACCUMULATED_OVER_ITERATIONS:
+            L.view(f, name)[...] += L.view(fk, name)
+        i64[ng:] += ik[ng:]                   # the event counters are running totals too (num_crossings is per species)
+    return RunResult(f, i64, per_species, stats, int(i64[ng + IC["STEPS_HELIX"]]), int(i64[ng + IC["STEPS_RETRO"]]),
+                     iter_finals, st, local_steps)
+

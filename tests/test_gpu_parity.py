@@ -569,6 +569,32 @@ def test_light_tally_readback():
     hb.destroy()
 
 
+def test_overlapped_iterations_equal_sequential():
+    """driver.run_overlapped: with a fixed shock profile the iterations are independent, so two of them share the GPU on
+    two contexts / streams / host threads.  Every iteration must be the one the sequential run computes (same populations,
+    same integer tallies per iteration, same iter_finalize results), and the merged state after the last one -- the last
+    iteration's buffer with the never-reset tallies summed over the contexts -- must equal the sequential run's."""
+    N, n_itrs, npc = 6000, 3, 14
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=n_itrs)
+    prob = mcs.inputs.build_problem(cfg)
+    hb = hip_backend(prob)
+    seq = mcs.driver.run(prob, hb, None, n_itrs=n_itrs, max_pcuts=npc, finalize=True)
+    hb.destroy()
+    bes = [hip_backend(prob), hip_backend(prob)]
+    ovl = mcs.driver.run_overlapped(prob, bes, n_itrs=n_itrs, max_pcuts=npc)
+    key = lambda r: [(s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in r.stats]
+    assert key(ovl) == key(seq)
+    assert np.array_equal(ovl.tallies_i64, seq.tallies_i64)
+    assert (ovl.steps_helix, ovl.steps_retro) == (seq.steps_helix, seq.steps_retro)
+    assert [s for _, _, s in ovl.local_steps] == [s for _, _, s in seq.local_steps]
+    assert_tallies_close(bes[0].layout, ovl.tallies_f64, seq.tallies_f64, TALLY_RTOL)
+    for (ia, fa, _), (ib, fb, _) in zip(ovl.iter_finals, seq.iter_finals):
+        assert ia == ib and abs(fa.Gamma_downstream / fb.Gamma_downstream - 1) < 1e-10
+        assert abs(fa.q_esc_cal_px - fb.q_esc_cal_px) <= 1e-10 * max(abs(fb.q_esc_cal_px), 1e-30)
+    for b in bes:
+        b.destroy()
+
+
 def test_linearity_in_the_weights():
     """Doubling all weights doubles every tally (power-of-two scaling is exact): 2e5 protons, 6 pcuts.
     (The full-size runs are in tests/test_gpu_full_size.py.)"""
