@@ -328,6 +328,9 @@ int mcs_final_download(mcs_ctx* ctx, int64_t n, int32_t* reason, int32_t* helix_
 double mcs_last_kernel_ms(mcs_ctx* ctx);
 /* launch geometry override: blocks (0 = auto), threads per block (0 = auto) */
 int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
+/* compute units of the context's device (the default grid of mcs_run_pcut* is 2 workgroups per CU; a caller that keeps two
+ * contexts busy on one device gives each of them one per CU: mcs_set_launch(ctx, mcs_num_cus(ctx), 256)) */
+int mcs_num_cus(mcs_ctx* ctx);
 
 #ifdef __cplusplus
 }

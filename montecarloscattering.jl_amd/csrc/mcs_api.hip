@@ -551,6 +551,8 @@ int mcs_init_pop_binned_strided(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t
   return 0;
 }
 
+int mcs_num_cus(mcs_ctx* c) { return c->n_cu; }
+
 int mcs_set_launch(mcs_ctx* c, int blocks, int threads) {
   if (threads != 0 && (threads % 64 != 0 || threads > 256)) return fail("mcs_set_launch: threads must be a multiple of 64, <= 256");
   c->blocks = blocks; c->threads = threads ? threads : 256;

@@ -372,7 +372,8 @@ ACCUMULATED_OVER_ITERATIONS = ("esc_flux", "px_esc_feb", "energy_esc_feb", "esc_
 
 
 def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pcuts: Optional[int] = None,
-                   on_iteration_end: Optional[Callable] = None, first_iter: int = 1) -> RunResult:
+                   on_iteration_end: Optional[Callable] = None, first_iter: int = 1,
+                   blocks_per_launch: Optional[int] = None) -> RunResult:
     """The iterations of a run with a FIXED shock profile (smooth-shocks = false -- the stock mc_in.toml, BASELINE
     config[1]) are independent Monte-Carlo realisations: nothing an iteration computes enters the next one's transport
     (src/main_loops.jl:52-121: every tally the transport reads is reset at the top; the RNG keys carry i_iter).  Their
@@ -381,6 +382,11 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
     tail, 40 % of an iteration at 10^6 particles) the blocks of the other's become resident on the CUs it has freed.
     Per-iteration results are those of run(): same keys, same populations; iter_finalize runs on the host in iteration
     order.  The tallies the reference never resets are sums over iterations and are merged over the contexts at the end.
+    blocks_per_launch: workgroups of a K1 launch while iterations overlap; default 2 x #CU / len(backends), i.e. with two
+    contexts ONE workgroup per CU each: the two launches are then resident side by side from the start (a CU holds two
+    workgroups), each SIMD carries one wave of either, and a wave whose neighbour is in its launch's tail issues at the
+    lone-wave rate -- measured 254 ms per iteration against 275 with full-chip launches, which let the other launch in only
+    as whole workgroups retire (tools/gpu_concurrent.py).
     Single process only (no communicator): collectives issued from two threads would need an order."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -393,6 +399,12 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
     sm = itf.SmoothingConfig(smooth_shocks=False)
     st = itf.IterState.create(prob, sm, P.n_itrs)
     locks = [threading.Lock() for _ in backends]
+    if blocks_per_launch is None and K > 1 and hasattr(backends[0], "num_cus"):
+        blocks_per_launch = max(2 * backends[0].num_cus() // K, 1)
+    if blocks_per_launch and K > 1:
+        for be in backends:
+            if hasattr(be, "set_launch"):
+                be.set_launch(int(blocks_per_launch), 256)
 
     def one(i_iter):
         k = (i_iter - first_iter) % K
@@ -423,6 +435,10 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
             if on_iteration_end is not None:
                 on_iteration_end(i_iter)
     # the state after the last iteration: its context's buffer, with the never-reset tallies summed over the contexts
+    if blocks_per_launch and K > 1:
+        for be in backends:
+            if hasattr(be, "set_launch"):
+                be.set_launch(0, 0)               # back to the automatic geometry
     k_last = (n_itrs - 1) % K
     f, i64 = backends[k_last].read_tallies()              # the only time the three histograms cross to the host
     for k in last:

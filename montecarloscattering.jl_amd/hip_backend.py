@@ -90,6 +90,9 @@ class HipBackend:
         """Live device tensors (f64, i64) holding the tallies, or None when the context owns them."""
         return self._bound
 
+    def num_cus(self) -> int:
+        return int(self.lib.mcs_num_cus(self.h))
+
     def set_launch(self, blocks: int = 0, threads: int = 0):
         self._chk(self.lib.mcs_set_launch(self.h, blocks, threads))
 

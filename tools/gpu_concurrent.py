@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import _mcs_loader; m = _mcs_loader.load()
 from mcs_amd import hip_backend
 N = int(sys.argv[1]); K = int(sys.argv[2]); NPC = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+BLOCKS = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # workgroups per launch in the concurrent leg (0: the default, 2 per CU)
 cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=8)
 prob = m.inputs.build_problem(cfg)
 bes = []
@@ -29,8 +30,10 @@ work(0, 1)
 t = time.time()
 for it in range(2, 2 + K): work(0, it)
 t_seq = time.time() - t
+if BLOCKS:
+    for b in bes: b.set_launch(BLOCKS, 256)
 t = time.time()
 th = [threading.Thread(target=work, args=(k, 2 + k)) for k in range(K)]
 [x.start() for x in th]; [x.join() for x in th]
 t_con = time.time() - t
-print(f"N={N} K={K}: sequential {t_seq:.3f} s ({t_seq/K*1e3:.0f} ms/iter), concurrent {t_con:.3f} s ({t_con/K*1e3:.0f} ms/iter), speedup {t_seq/t_con:.2f}")
+print(f"N={N} K={K} blocks={BLOCKS or 512}: sequential {t_seq:.3f} s ({t_seq/K*1e3:.0f} ms/iter), concurrent {t_con:.3f} s ({t_con/K*1e3:.0f} ms/iter), speedup {t_seq/t_con:.2f}")
