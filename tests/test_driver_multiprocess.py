@@ -120,3 +120,29 @@ def test_oracle_strided_init_and_indexed_run():
     assert ns == int(lsave[sel].sum())
     assert np.array_equal(ob.saved_gidx().numpy(), sel[lsave[sel] == 1])
     ob.destroy()
+
+
+def test_overlapped_iterations_equal_sequential_on_the_oracle():
+    """driver.run_overlapped with the CPU oracle as backend (two contexts, two host threads): every iteration is the one the
+    sequential run computes and the merged final state equals the sequential one (the GPU form of this test is
+    test_overlapped_iterations_equal_sequential)."""
+    from conftest import assert_tallies_close
+    N, n_itrs, npc = 300, 3, 9
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=n_itrs)
+    prob = mcs.inputs.build_problem(cfg)
+    be = orc.OracleBackend(mcs.capi, "det", 1); be.create(prob)
+    seq = mcs.driver.run(prob, be, None, n_itrs=n_itrs, max_pcuts=npc, finalize=True)
+    be.destroy()
+    bes = [orc.OracleBackend(mcs.capi, "det", 1), orc.OracleBackend(mcs.capi, "det", 1)]
+    for b in bes:
+        b.create(prob)
+    ovl = mcs.driver.run_overlapped(prob, bes, n_itrs=n_itrs, max_pcuts=npc)
+    key = lambda r: [(s.i_iter, s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in r.stats]
+    assert key(ovl) == key(seq)
+    assert np.array_equal(ovl.tallies_i64, seq.tallies_i64)
+    assert [s for _, _, s in ovl.local_steps] == [s for _, _, s in seq.local_steps]
+    assert_tallies_close(mcs.capi.Layout(prob.params), ovl.tallies_f64, seq.tallies_f64, rtol=1e-12)
+    for (ia, fa, _), (ib, fb, _) in zip(ovl.iter_finals, seq.iter_finals):
+        assert ia == ib and abs(fa.Gamma_downstream / fb.Gamma_downstream - 1) < 1e-12
+    for b in bes:
+        b.destroy()
