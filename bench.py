@@ -28,6 +28,9 @@ Extra objects in the JSON line:
                the same code on one core (the reference itself is serial), smaller sample.
   load_balance (N > 1) the largest local population over the mean, per pcut: worst and
                step-weighted mean over the timed iterations.
+  overlapped_iterations  (N = 1) a separate leg AFTER the timed region, never part of `value`: the same iterations
+               with two of them in flight on two contexts / streams (driver.run_overlapped) -- possible because the
+               workload's shock profile is fixed, so its iterations are independent; --overlap 1 skips it.
 """
 import argparse
 import json
