@@ -401,17 +401,27 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
     locks = [threading.Lock() for _ in backends]
     if blocks_per_launch is None and K > 1 and hasattr(backends[0], "num_cus"):
         blocks_per_launch = max(2 * backends[0].num_cus() // K, 1)
-    if blocks_per_launch and K > 1:
-        for be in backends:
-            if hasattr(be, "set_launch"):
-                be.set_launch(int(blocks_per_launch), 256)
+
+    state = {"busy": 0, "started": 0}
+    state_lock = threading.Lock()
 
     def one(i_iter):
         k = (i_iter - first_iter) % K
         with locks[k]:                       # a context carries one iteration at a time
             be = backends[k]
-            res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False)
-            ion_fin = consumers.ion_finalize(prob, be, len(cfg.species))     # K4, before the context is reused
+            with state_lock:
+                state["started"] += 1
+                # the last iteration of an odd count has the chip to itself: the automatic geometry again
+                alone = state["busy"] == 0 and state["started"] == n_itrs
+                state["busy"] += 1
+            if blocks_per_launch and K > 1 and hasattr(be, "set_launch"):
+                be.set_launch(0 if alone else int(blocks_per_launch), 0 if alone else 256)
+            try:
+                res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False)
+                ion_fin = consumers.ion_finalize(prob, be, len(cfg.species))     # K4, before the context is reused
+            finally:
+                with state_lock:
+                    state["busy"] -= 1
         return k, res, ion_fin
 
     stats, per_species, iter_finals, local_steps = [], [], [], []
