@@ -328,6 +328,16 @@ int mcs_final_download(mcs_ctx* ctx, int64_t n, int32_t* reason, int32_t* helix_
 double mcs_last_kernel_ms(mcs_ctx* ctx);
 /* launch geometry override: blocks (0 = auto), threads per block (0 = auto) */
 int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
+/* Sliced tail of mcs_run_pcut* (0 = off: one launch per pcut).  A launch cannot end before its longest history does, and
+ * a history is up to 10^4 sequential passes (src/particle_loop.jl:162) while the bulk of a 10^6-particle pcut takes the
+ * chip a few thousand: with budget_trips > 0 every wave that has found the work queue empty makes budget_trips more
+ * trips through its loop (6 passes each), writes the complete lane state of its live particles to a device buffer and
+ * ends; the library relaunches them spread over the chip's waves -- a particle that shares its wave with few others
+ * advances faster, its neighbours' rare work no longer stalls it -- until none is left.  A history is the same bit for
+ * bit however often it is suspended (state and RNG stream position travel with the particle).
+ * mcs_last_launches: launches the last mcs_run_pcut* took. */
+int mcs_set_tail_slicing(mcs_ctx* ctx, int budget_trips);
+int mcs_last_launches(mcs_ctx* ctx);
 /* compute units of the context's device (the default grid of mcs_run_pcut* is 2 workgroups per CU; a caller that keeps two
  * contexts busy on one device gives each of them one per CU: mcs_set_launch(ctx, mcs_num_cus(ctx), 256)) */
 int mcs_num_cus(mcs_ctx* ctx);

@@ -82,6 +82,12 @@ struct mcs_ctx {
   const long long* idx_gidx = nullptr;       // ... or idx_gidx[k] (mcs_run_pcut_indexed; caller-owned device memory)
   bool debug_finals = false;   // mcs_set_debug_finals: record per-particle end states (tests)
   int retro_cap = MCS_RETRO_CAP;
+  // sliced tail (mcs_set_tail_slicing; KArgs "sliced launches"): after the queue is exhausted a wave makes tail_budget more trips,
+  // exports its live particles and ends; the host relaunches them, spread over the chip's waves, until none is left
+  int tail_budget = 0;         // trips; 0 = one launch per pcut, run to the end
+  int tail_rounds_last = 0;    // launches the last mcs_run_pcut* took
+  int claim_max_first = 64;    // MCS_CLAIM_MAX=<n> (environment): live particles per wave in the FIRST launch of a pcut (measurements of tau(L))
+  double* d_strag[2] = {nullptr, nullptr}; long long strag_cap = 0;
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
   int refill_min = 12;         // MCS_REFILL_MIN=<n> (environment) overrides: A/B measurements
   int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
@@ -247,41 +253,54 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   if (device < 0 || device >= ndev) return fail("mcs_create: device ordinal out of range");
   HIPCHK(hipSetDevice(device));
   mcs_ctx* c = new mcs_ctx();
+  // from here on a failing HIP call must not leak the context and what it has allocated so far
+#define CRCHK(expr)                                                                          \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      const std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+      (void)mcs_destroy(c);                                                                  \
+      return fail(m_);                                                                       \
+    }                                                                                        \
+  } while (0)
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_TAIL_BUDGET"); if (e && std::atoi(e) >= 0) c->tail_budget = std::atoi(e); }
+  { const char* e = std::getenv("MCS_CLAIM_MAX"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->claim_max_first = std::atoi(e); }
   { const char* e = std::getenv("MCS_REFILL_MIN"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 48) c->refill_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_DEFER_K"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 40) c->defer_k = std::atoi(e); }
   c->P = *p;
   mcs_tally_layout(p, &c->L);
   c->device = device;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-  else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+  else { CRCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
   hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, device));
+  CRCHK(hipGetDeviceProperties(&prop, device));
   c->n_cu = prop.multiProcessorCount;
   const int ne = p->n_grid + 2;
-  HIPCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
+  CRCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
+  CRCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
+  CRCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
   { const char* e = std::getenv("MCS_TALLY_REPLICAS_OFF"); c->tally_replicas = !(e && e[0] == '1'); }
   if (c->tally_replicas) {
     c->rep_n = c->L.total;     // the whole tally buffer: the three big histograms are 99 % of it
     const size_t nrep = (size_t)MCS_TALLY_REPLICAS * (size_t)c->rep_n;
-    HIPCHK(hipMalloc((void**)&c->d_tally_rep, nrep * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));
+    CRCHK(hipMalloc((void**)&c->d_tally_rep, nrep * sizeof(double)));
+    CRCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));
   }
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
-  HIPCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
+  CRCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  CRCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
+  CRCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
   c->own_T = c->own_I = true;
-  HIPCHK(hipMemsetAsync(c->d_T, 0, (size_t)c->L.total * sizeof(double), c->stream));
-  HIPCHK(hipMemsetAsync(c->d_I, 0, (size_t)mcs_i64_total(p) * sizeof(unsigned long long), c->stream));
-  HIPCHK(hipEventCreate(&c->ev0));
-  HIPCHK(hipEventCreate(&c->ev1));
+  CRCHK(hipMemsetAsync(c->d_T, 0, (size_t)c->L.total * sizeof(double), c->stream));
+  CRCHK(hipMemsetAsync(c->d_I, 0, (size_t)mcs_i64_total(p) * sizeof(unsigned long long), c->stream));
+  CRCHK(hipEventCreate(&c->ev0));
+  CRCHK(hipEventCreate(&c->ev1));
 
-  HIPCHK(hipStreamSynchronize(c->stream));
+  CRCHK(hipStreamSynchronize(c->stream));
+#undef CRCHK
   *out = c;
   return 0;
 }
@@ -293,7 +312,7 @@ int mcs_destroy(mcs_ctx* c) {
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
                   c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_tally_rep,
-                  c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag};
+                  c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag, c->d_strag[0], c->d_strag[1]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
@@ -453,7 +472,7 @@ int mcs_pop_upload(mcs_ctx* c, int64_t n, const mcs_soa* host) {
       return fail("mcs_pop_upload: weight, ptot_pf, pb_pf, x_PT_cm, prp_x_cm, acctime_sec and phi_rad must be finite");
     if (!(host->xn_per[k] > 0) || !std::isfinite(host->xn_per[k])) return fail("mcs_pop_upload: xn_per must be finite and > 0");
   }
-  c->n = 0;
+  c->n = 0; c->n_run_last = -1; c->n_saved_last = 0; c->idx_gidx = nullptr;   // the saved arrays / src[] of the last run no longer describe this population
   if (ensure_capacity(c, n)) return 1;
   if (n > 0 && upload_soa(c, c->cur, n, host)) return 1;
   c->n = n;
@@ -470,7 +489,10 @@ int mcs_saved_download(mcs_ctx* c, int64_t n, mcs_soa* host, uint8_t* l_save) {
   if (host && download_soa(c, c->sav, n, host)) return 1;
   std::vector<uint8_t> own;
   if (!l_save && host) { own.resize((size_t)n); l_save = own.data(); }
-  if (l_save) { HIPCHK(hipMemcpyAsync(l_save, c->d_lsave, (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+  if (l_save) {
+    HIPCHK(hipMemcpyAsync(l_save, c->d_lsave, (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t k = 0; k < n; ++k) l_save[k] = l_save[k] == 1;      // (the device byte is a status: 1 saved, 2 ended)
+  }
   if (host) {       // the *_saved arrays of the reference hold zeros where nothing was saved (main_loops.jl:184-197)
     for (int64_t k = 0; k < n; ++k) {
       if (l_save[k]) continue;
@@ -492,7 +514,7 @@ int mcs_init_pop(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t n_total, const
   for (int64_t k = 0; k < n; ++k)
     if (!(ptot_pf_in[k] > 0) || !std::isfinite(ptot_pf_in[k]) || !std::isfinite(weight_in[k]))
       return fail("mcs_init_pop: ptot_pf must be finite and > 0 (reference quirk G6), weight finite");
-  c->n = 0;
+  c->n = 0; c->n_run_last = -1; c->n_saved_last = 0; c->idx_gidx = nullptr;   // the saved arrays / src[] of the last run no longer describe this population
   if (ensure_capacity(c, n)) return 1;
   if (ensure_stage(c, 2 * n + 2)) return 1;
   if (n > 0) {
@@ -531,7 +553,7 @@ int mcs_init_pop_binned_strided(mcs_ctx* c, int64_t n, int64_t j_offset, int64_t
       return fail("mcs_init_pop_binned: ptot_pf must be finite and > 0 (reference quirk G6), weight finite");
   }
   if (!std::isfinite(x_start_cm)) return fail("mcs_init_pop_binned: x_start_cm must be finite");
-  c->n = 0;
+  c->n = 0; c->n_run_last = -1; c->n_saved_last = 0; c->idx_gidx = nullptr;   // the saved arrays / src[] of the last run no longer describe this population
   if (ensure_capacity(c, n)) return 1;
   const size_t nd = (size_t)3 * n_bins + 1;      // ptot | weight | start (int64 in a double slot)
   if (ensure_stage(c, (long long)nd + 2)) return 1;
@@ -560,6 +582,12 @@ int mcs_set_launch(mcs_ctx* c, int blocks, int threads) {
 }
 
 int mcs_set_debug_finals(mcs_ctx* c, int on) { c->debug_finals = on != 0; return 0; }
+int mcs_set_tail_slicing(mcs_ctx* c, int budget_trips) {
+  if (budget_trips < 0 || budget_trips > (1 << 24)) return fail("mcs_set_tail_slicing: budget out of range");
+  c->tail_budget = budget_trips;
+  return 0;
+}
+int mcs_last_launches(mcs_ctx* c) { return c->tail_rounds_last; }
 int mcs_set_retro_cap(mcs_ctx* c, int64_t cap) {
   if (cap < 0 || cap > 2000000000LL) return fail("mcs_set_retro_cap: cap out of range");
   c->retro_cap = cap > 0 ? (int)cap : MCS_RETRO_CAP;
@@ -592,7 +620,13 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // exports read saved entries through the compacted index list, and mcs_saved_download zeroes the entries of unsaved
   // particles in the host copy it hands out (nine fills per pcut less in the timed path).
   if (n > 0) HIPCHK(hipMemsetAsync(c->d_lsave, 0, (size_t)n, c->stream));
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+  const int budget = (c->P.state_fp32 || n == 0) ? 0 : c->tail_budget;      // (the fp32 study kernel is not sliced)
+  if (budget > 0 && !c->d_strag[0]) {
+    // one entry per lane a launch can hold: 2 workgroups of 256 threads per CU
+    c->strag_cap = (long long)2 * c->n_cu * 256;
+    for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void**)&c->d_strag[b], (size_t)c->strag_cap * MCS_STRAG_WORDS * sizeof(double)));
+  }
 
   KArgs& a = c->h_args;
   std::memset(&a, 0, sizeof(a));
@@ -620,38 +654,81 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   a.wait_full = c->park ? 1 : 0;
   a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
   if (c->debug_finals) { a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x; }
+  a.claim_max = 64; a.budget_trips = budget; a.strag_count = c->d_counters + 3;
+  a.strag_out = c->d_strag[0];
 
   const int threads = c->threads;
   int blocks = c->blocks;
+  // two 256-thread blocks are resident per CU (78 KB of LDS each); the fp32-state kernel (27 KB, 119 VGPRs) fits four
+  const long long full = (long long)c->n_cu * (c->P.state_fp32 ? 4 : 2);
   if (blocks <= 0) {
     // persistent lanes: fill the chip, never launch more lanes than particles
     const long long want = (n + threads - 1) / threads;
-    // two 256-thread blocks are resident per CU (78 KB of LDS each); the fp32-state kernel (27 KB, 119 VGPRs) fits four
-    const long long full = (long long)c->n_cu * (c->P.state_fp32 ? 4 : 2);
     blocks = (int)(want < full ? want : full);
     if (blocks < 1) blocks = 1;
   }
-  HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  if (c->claim_max_first < 64 && !c->P.state_fp32) {
+    a.claim_max = c->claim_max_first; a.defer_k = 1; a.wait_full = 0; a.tail_merge = 0;
+    const long long per_block = (long long)(threads / 64) * a.claim_max;
+    const long long nb = (n + per_block - 1) / per_block;
+    if (c->blocks <= 0) blocks = (int)(nb < full ? (nb > 0 ? nb : 1) : full);
+  }
+  if (budget > 0 && (long long)blocks * threads > c->strag_cap) return fail("mcs_run_pcut: launch geometry exceeds the export buffer of a sliced run");
   // the specialised kernel for the common configuration (see transport_body<PLAIN> in mcs_transport.hip)
   const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                      !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
-  if (n > 0) {
-    if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, blocks, 256, c->stream));
-    else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
-    c->rep_dirty = true;
+  double ms_total = 0.0;
+  c->tail_rounds_last = 0;
+  for (int round = 0;; ++round) {
+    HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (n > 0) {
+      if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, blocks, 256, c->stream));
+      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
+      c->rep_dirty = true;
+    }
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    ++c->tail_rounds_last;
+    if (budget == 0) break;
+    // sliced run: how many particles did the launch export?  They are the next launch's queue, spread over the chip's waves:
+    // a pass costs a wave the same with 1 live lane as with 64, but the rare work of every live lane stalls all the others,
+    // so the fewer particles share a wave the faster each history advances -- and the launch waits for its longest one.
+    unsigned long long n_x = 0;
+    HIPCHK(hipMemcpyAsync(&n_x, c->d_counters + 3, sizeof(n_x), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms_r = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms_r, c->ev0, c->ev1));
+    ms_total += ms_r;
+    if (n_x == 0) break;
+    if ((long long)n_x > c->strag_cap) return fail("mcs_run_pcut: export buffer overrun");
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));        // work counter
+    HIPCHK(hipMemsetAsync(c->d_counters + 3, 0, sizeof(unsigned long long), c->stream));    // export counter
+    a.strag_in = c->d_strag[round & 1]; a.strag_out = c->d_strag[(round + 1) & 1];
+    a.n_resume = (long long)n_x; a.fresh_lo = n;
+    const long long waves = full * (threads / 64);
+    long long cm = ((long long)n_x + waves - 1) / waves;
+    if (cm >= 32) cm = 64;
+    a.claim_max = (int)cm;
+    if (cm < 64) { a.defer_k = 1; a.wait_full = 0; a.tail_merge = 0; }
+    const long long per_block = (long long)(threads / 64) * cm;
+    long long nb = ((long long)n_x + per_block - 1) / per_block;
+    blocks = (int)(nb < full ? nb : full);
+    // one particle per wave and at most one wave per SIMD: nothing left to gain from another slice
+    a.budget_trips = ((long long)n_x <= (long long)c->n_cu * (threads / 64)) ? 0 : budget;
   }
-  HIPCHK(hipEventRecord(c->ev1, c->stream));
   // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
   // independent count of the l_save flags next to the kernel's own n_saved counter, read back together
   HIPCHK(mcs_launch_compact(c->d_lsave, n, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src, c->stream));
   unsigned long long ns[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  c->last_ms = ms;
+  if (budget == 0) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    ms_total = ms;
+  }
+  c->last_ms = ms_total;
   c->n_saved_last = (long long)ns[0];
   c->n_run_last = n; c->idx_first = i_prt_offset; c->idx_stride = i_prt_stride; c->idx_gidx = (const long long*)dev_gidx;
   // every entry point that hands out l_save or the saved arrays goes through here (a spilling build of the kernel

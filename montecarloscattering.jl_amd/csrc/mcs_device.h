@@ -56,6 +56,18 @@ struct KArgs {
   int defer_k;               // lanes with pending rare work a wave collects before entering the rare region (MCS_DEFER_K; 1 = never wait)
   int retro_cap;             // inner steps after which one retro_time walk is ended (MCS_RETRO_CAP; tests lower it)
   int tail_merge;            // 1: sparse waves of a block consolidate after exhaustion (MCS_TAIL_MERGE=0 turns it off)
+  // ---- sliced launches (DESIGN.md "Sliced tail"): a launch's queue is [resume list | fresh index range]; a wave that has found
+  // the queue exhausted makes `budget_trips` more trips through the loop header, then writes the complete lane state of its
+  // live particles to `strag_out` and ends; a later launch resumes them.  State and RNG stream position travel with the
+  // particle (the mailbox format of the tail consolidation), so a history is the same however often it is suspended.
+  const double* strag_in;    // lane states to resume first: entry e at strag_in[e * MCS_STRAG_WORDS ..]
+  long long n_resume;        // entries of strag_in
+  long long fresh_lo;        // then the fresh particles fresh_lo .. n-1 of `in` (queue position c >= n_resume is particle fresh_lo + c - n_resume)
+  double* strag_out;         // where this launch exports to (same layout; room for one entry per lane of the launch)
+  unsigned long long* strag_count;   // entries written to strag_out (device counter, zeroed by the host)
+  int budget_trips;          // 0: no export, every wave runs its particles to their end
+  int claim_max;             // live particles a wave holds at most (64; less spreads a sparse queue over the waves of the chip:
+                             // a pass costs a wave the same with 1 live lane as with 64, but every live lane's rare work stalls the others)
 };
 
 // Replicas of the tally buffer.  Particles of one population pile their tallies onto
@@ -68,6 +80,7 @@ struct KArgs {
 
 // zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old
+#define MCS_STRAG_WORDS 36   // doubles per exported lane state (state_store in mcs_transport.hip)
 #define MCS_EV_CAP 192       // records per wave: < 64 after the drain + at most 2 per lane in one pass
 
 #endif

@@ -49,7 +49,7 @@ mcs_k_count_saved(const uint8_t* __restrict__ l_save, long long n, unsigned int*
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long i = base + r * 256 + threadIdx.x;
-    const bool f = i < n && l_save[i] != 0;
+    const bool f = i < n && l_save[i] == 1;
     c += (unsigned int)__popcll(__ballot(f));     // wave-uniform count
   }
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -96,7 +96,7 @@ mcs_k_compact_index(const uint8_t* __restrict__ l_save, long long n, const unsig
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long i = base + r * 256 + threadIdx.x;
-    f[r] = i < n && l_save[i] != 0;
+    f[r] = i < n && l_save[i] == 1;
     m[r] = __ballot(f[r]);
     if (lane == 0) wcount[r][wave] = (unsigned int)__popcll(m[r]);
   }

@@ -1150,11 +1150,12 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
   if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt, capped);
   TTG_MARK(44);
   if (i_return == 0) {
+    if (capped) return 3;      // MCS_RETRO_CAP: ends like an aged-out particle -- nothing added to the downstream sums (as the oracle)
     double vel = p.ptot_pf / h.m;
     if ((p.gam_pf - 1) >= MCS_E_REL_PT) vel /= p.gam_pf;
     sadd(0, p.ptot_pf / 3 * vel * p.weight * a->density);
     sadd(1, (p.gam_pf - 1) * h.m * (CC_ * CC_) * p.weight * a->density);
-    return capped ? 3 : (lose_pt ? 4 : 1);
+    return lose_pt ? 4 : 1;
   }
   // the particle goes on: what the next pass has to know
   int f = p.flags | F_CHECK;
@@ -1392,33 +1393,38 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
 #define MCS_MB_SLOTS 32
 #define MCS_MB_WORDS 36
 static_assert(MCS_MB_WORDS * MCS_MB_SLOTS <= MCS_EV_F64 * MCS_EV_CAP, "the mailbox lives in the donor's record stack");
+static_assert(MCS_MB_WORDS == MCS_STRAG_WORDS, "the export buffers of a sliced run hold the same lane state");
 __shared__ unsigned int S_msimd[4];     // SIMD id of each wave (HW_REG_HW_ID[5:4])
 __shared__ unsigned int S_mlive[4];     // live lanes an exhausted receiver last published (64 before that)
 __shared__ unsigned int S_mstate[2];    // per SIMD pair: 0 open, 1 donated, 2 closed
 __shared__ unsigned int S_mcount[2];    // particles in the mailbox
 
+// STRIDE: MCS_MB_SLOTS for the LDS mailbox (word-major); 1 for the export buffers in global memory (entry-major: one
+// address register per lane, every word at an immediate offset)
 template <int STRIDE>
 __device__ __forceinline__ void state_store(double* mb, const Pt& p, const Rng& rng, long long k, int evw, double phi_prev) {
+  constexpr int S_ = STRIDE;
   const double v[30] = {p.weight, p.ptot_pf, p.pb_pf, p.p_perp, p.gam_pf, p.x, p.x_old, p.phi, p.prp, p.acctime, p.xn_per, p.dphi,
                         p.gyro_denom, p.gyro_rad, p.gyro_rad_tot, p.gyro_period, p.t_step, p.rp_val, p.cm_val, p.rg_val, p.x_dt,
                         p.t_ev, p.z_gsf, p.z_bcos, p.z_ux, p.z_gef, p.z_lo, p.z_hi, phi_prev, 0.0};
 #pragma unroll
-  for (int j = 0; j < 30; ++j) mb[j * STRIDE] = v[j];
-  mb[30 * STRIDE] = __longlong_as_double(k);
+  for (int j = 0; j < 30; ++j) mb[j * S_] = v[j];
+  mb[30 * S_] = __longlong_as_double(k);
   const int gridpack = p.i_grid | (p.i_grid_old << 8) | (p.ig3 << 16) | (p.tcut << 24);
   const int bits = p.ovr_inc | ((int)p.downstream << 1) | ((int)p.inj << 2) | ((evw & 7) << 3);
-  mb[31 * STRIDE] = __hiloint2double(p.flags, (int)p.n_ovr);
-  mb[32 * STRIDE] = __hiloint2double(gridpack, p.helix);
-  mb[33 * STRIDE] = __hiloint2double(p.n_retro, bits);
-  mb[34 * STRIDE] = __hiloint2double((int)rng.k0, (int)rng.k1);
-  mb[35 * STRIDE] = __hiloint2double((int)rng.n, 0);
+  mb[31 * S_] = __hiloint2double(p.flags, (int)p.n_ovr);
+  mb[32 * S_] = __hiloint2double(gridpack, p.helix);
+  mb[33 * S_] = __hiloint2double(p.n_retro, bits);
+  mb[34 * S_] = __hiloint2double((int)rng.k0, (int)rng.k1);
+  mb[35 * S_] = __hiloint2double((int)rng.n, 0);
 }
 template <int STRIDE, bool COHERENT>
 __device__ __forceinline__ void state_load(const double* mb, Pt& p, Rng& rng, long long& k, int& evw, double& phi_prev) {
+  constexpr int S_ = STRIDE;
   // COHERENT: the wave reads back what it stored to global memory earlier -- agent-scope loads, past the L1
   auto LD = [&](int j) -> double {
-    if (COHERENT) return __hip_atomic_load(mb + j * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return mb[j * STRIDE];
+    if (COHERENT) return __hip_atomic_load(mb + j * S_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mb[j * S_];
   };
   double unused__;
   double* const d[30] = {&p.weight, &p.ptot_pf, &p.pb_pf, &p.p_perp, &p.gam_pf, &p.x, &p.x_old, &p.phi, &p.prp, &p.acctime, &p.xn_per,
@@ -1605,7 +1611,13 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   double phi_prev = 0.0;  // phase before the last move (the no-DSA retry loop needs it)
   long long k = -1;
   const unsigned lane = __lane_id();
-  const unsigned long long n = (unsigned long long)a->n;
+  // the launch's queue: first the resume list (lane states a previous launch exported), then the fresh particles
+  // fresh_lo .. n-1 of the population (see KArgs: sliced launches)
+  const unsigned long long n_resume = (unsigned long long)a->n_resume;
+  const unsigned long long n = n_resume + (unsigned long long)(a->n - a->fresh_lo);
+  const unsigned budget = (unsigned)__builtin_amdgcn_readfirstlane(a->budget_trips);
+  const int claim_max = __builtin_amdgcn_readfirstlane(a->claim_max);
+  unsigned mtick_ex = 0;            // mtick when this wave found the queue exhausted
 
   const unsigned wv = threadIdx.x >> 6;
   // tail consolidation (see mb_store): role of this wave, decided once
@@ -1643,7 +1655,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const bool waiting_on = __builtin_amdgcn_readfirstlane((int)(a->wait_full != 0 && blockDim.x == 256u)) != 0;
   // idle + waiting lanes at which the wave has housekeeping to do: MCS_REFILL_MIN while there is unclaimed work;
   // afterwards 64 (nothing left: the wave ends)
-  const unsigned refill_min = (unsigned)__builtin_amdgcn_readfirstlane(a->refill_min);   // MCS_REFILL_MIN unless overridden (A/B runs)
+  // (a wave that may hold only claim_max < 64 particles -- a sparse queue spread over the chip -- refills as soon as one of its
+  // claim_max places is free: the host turns deferral and waiting off for such launches)
+  const unsigned refill_min = claim_max < 64 ? (unsigned)(64 - claim_max + 1)
+                                             : (unsigned)__builtin_amdgcn_readfirstlane(a->refill_min);   // MCS_REFILL_MIN unless overridden (A/B runs)
   unsigned refill_at = refill_min;
   unsigned ev_pending = 0;          // wave-uniform mirror of S_evcur[wv] (no LDS round trip per pass)
   // ---- tail ring.  After the work counter is exhausted a wave decays to a handful of live particles, and an instruction
@@ -1688,7 +1703,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // refill idle lanes (wave-aggregated claim)
       const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(active);
       if ((unsigned)n_idle + n_wait >= refill_min && !exhausted && idle != 0ull) {
-        const int nidle = __popcll(idle);
+        const int nfree = __popcll(idle);
+        int nidle = nfree < claim_max - (64 - nfree) ? nfree : claim_max - (64 - nfree);    // places to fill: at most claim_max live
+        nidle = nidle > 0 ? nidle : 0;
         const int leader = __ffsll((long long)idle) - 1;
         unsigned long long base = 0;
         if ((int)lane == leader) base = atomicAdd(a->work_counter, (unsigned long long)nidle);
@@ -1697,7 +1714,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           exhausted = true;
           defer_k = 1u;
           ring_on = __builtin_amdgcn_readfirstlane(a->tail_ring) != 0;
-          if (mrole != 0) mpoll_mask = MCS_MERGE_POLL_MASK;
+          mtick_ex = mtick;
+          if (mrole != 0 || budget != 0u) mpoll_mask = MCS_MERGE_POLL_MASK;
 #ifdef MCS_PROF_TAIL
           if (lane == 0) S_ttgate[wv] = 1u;
 #endif
@@ -1707,13 +1725,38 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         } else if (!active) {
           const int rank = (int)below(idle);
           const unsigned long long idx = base + (unsigned long long)rank;
-          if (idx < n) {
-            k = (long long)idx;
+          if (rank < nidle && idx >= n_resume && idx < n) {
+            k = a->fresh_lo + (long long)(idx - n_resume);
             load_particle(a, s, h, k, p, rng);
             act = -1; evw = 0; rb = 0u - 256u;
             // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
             // every outstanding store and no-return tally atomic)
             __builtin_amdgcn_s_waitcnt(0x0F70);
+          }
+        }
+        // the head of the queue: particles an earlier launch exported.  Their lane states come in through the wave's record
+        // stack, used as a mailbox exactly as in the tail consolidation (pending records are tallied first); up to
+        // MCS_MB_SLOTS at a time.  (Through LDS because 36 global loads per lane in this loop cost ~100 spilled registers.)
+        if (!exhausted && __builtin_amdgcn_readfirstlane(base < n_resume ? 1 : 0)) {
+          drain_events(a, s, wv, lane, true); ev_pending = 0u;
+          const unsigned long long left = n_resume - base;
+          const unsigned cnt_r = (unsigned)(left < (unsigned long long)nidle ? left : (unsigned long long)nidle);
+          const unsigned rank = below(idle);
+          double* const box = &S_evf[wv][0][0];
+          for (unsigned b0 = 0; b0 < cnt_r; b0 += MCS_MB_SLOTS) {
+            const unsigned cb = cnt_r - b0 < MCS_MB_SLOTS ? cnt_r - b0 : MCS_MB_SLOTS;
+            const double* src = a->strag_in + (base + b0) * MCS_STRAG_WORDS;
+            for (unsigned i = lane; i < MCS_MB_WORDS * MCS_MB_SLOTS; i += 64u) {
+              const unsigned j = i / MCS_MB_SLOTS, r = i % MCS_MB_SLOTS;
+              if (r < cb) box[i] = src[r * MCS_STRAG_WORDS + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!active && rank >= b0 && rank < b0 + cb) {
+              mb_load(wv, rank - b0, p, rng, k, evw, phi_prev);
+              refresh_thr(h, p);
+              act = -1; rb = rng.n - 256u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           }
         }
         PROF_ADD(5, 1); PROF_ADD(6, nidle);
@@ -1730,8 +1773,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           rb = rng.n - 256u;
           act = -1;
         }
-        mrole = 0; mpoll_mask = ~0u;
+        mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;
       };
+      // (a sliced launch whose budget is spent exports below: the pair is closed first, a donation already made is taken and exported too)
+      const bool closing = budget != 0u && exhausted && mtick - mtick_ex >= budget;
       if (mrole != 0 && exhausted) {
         unsigned mpartner;
         const unsigned mpair = pair_of(mpartner);
@@ -1742,18 +1787,18 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           unsigned st = 0u;
           if (lane == 0) {
             S_mlive[wv] = (unsigned)nlive;
-            st = nlive == 0 ? atomicCAS(&S_mstate[mpair], 0u, 2u) : __hip_atomic_load(&S_mstate[mpair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            st = (nlive == 0 || closing) ? atomicCAS(&S_mstate[mpair], 0u, 2u) : __hip_atomic_load(&S_mstate[mpair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
           if (st == 1u) {
             take_donation(mpair, mpartner);
             if (lane == 0) S_mstate[mpair] = 2u;
-          } else if (st == 2u || nlive == 0) { mrole = 0; mpoll_mask = ~0u; }
+          } else if (st == 2u || nlive == 0 || closing) { mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u; }
         } else {
           const int room = 64 - (int)__builtin_amdgcn_readfirstlane((int)S_mlive[mpartner]);
-          if (nlive == 0) {
+          if (nlive == 0 || closing) {
             if (lane == 0) (void)atomicCAS(&S_mstate[mpair], 0u, 2u);     // nothing to give: the receiver stops polling
-            mrole = 0; mpoll_mask = ~0u;
+            mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;
           } else if (nlive <= MCS_MB_SLOTS && nlive <= room) {
             // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
             drain_events(a, s, wv, lane, true); ev_pending = 0u;
@@ -1767,9 +1812,38 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             if (st == 0u) {          // handed over: this wave is done
               act = 0; p.flags = 0; p.helix = 0; evw = 0;
             }
-            mrole = 0; mpoll_mask = ~0u;     // (st == 2: the receiver had already left -- carry on alone)
+            mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;     // (st == 2: the receiver had already left -- carry on alone)
           }
         }
+      }
+      // ---- sliced launches: the budget of trips after exhaustion is spent -- the live particles go to the export buffer
+      // (complete lane state, mid-history) and the wave ends; a later launch resumes them
+      if (closing) {
+        const unsigned long long am_x = __builtin_amdgcn_ballot_w64(active);
+        if (am_x != 0ull) {
+          const int nlive = __popcll(am_x);
+          const int leader = __ffsll((long long)am_x) - 1;
+          unsigned long long base = 0;
+          if ((int)lane == leader) base = atomicAdd(a->strag_count, (unsigned long long)nlive);
+          base = __shfl(base, leader);
+          // (through the record stack as a mailbox, MCS_MB_SLOTS particles at a time: see the import above)
+          drain_events(a, s, wv, lane, true); ev_pending = 0u;
+          const unsigned rank = below(am_x);
+          double* const box = &S_evf[wv][0][0];
+          for (unsigned b0 = 0; b0 < (unsigned)nlive; b0 += MCS_MB_SLOTS) {
+            const unsigned cb = (unsigned)nlive - b0 < MCS_MB_SLOTS ? (unsigned)nlive - b0 : MCS_MB_SLOTS;
+            if (active && rank >= b0 && rank < b0 + cb) mb_store(wv, rank - b0, p, rng, k, evw, phi_prev);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double* dst = a->strag_out + (base + b0) * MCS_STRAG_WORDS;
+            for (unsigned i = lane; i < MCS_MB_WORDS * MCS_MB_SLOTS; i += 64u) {
+              const unsigned j = i / MCS_MB_SLOTS, r = i % MCS_MB_SLOTS;
+              if (r < cb) dst[r * MCS_STRAG_WORDS + j] = box[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+          act = 0; p.flags = 0; p.helix = 0; evw = 0;
+        }
+        mrole = 0;
       }
       if (exhausted) refill_at = 64u;
       // nothing left: the loop ends after this pass (which computes on idle lanes and stores nothing) -- no jump
@@ -1934,12 +2008,15 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           a->sv.acctime_sec[k] = p.acctime; a->sv.phi_rad[k] = p.phi;
           a->sv.meta[k] = mcs_pack_meta(p.i_grid, p.tcut, p.downstream, p.inj);
           cnt(a, MCS_IC_COUNT);
-        } else if (p.npush < 2) {
-          // particle_finish! (transform, two bin look-ups, up to five tallies) is deferred like the zone-crossing
-          // tallies: a record on the wave's stack, tallied 64 at a time (a lane pushes at most two records per pass)
-          push_record(p, p.ig3, -1, (1u << 28) | ((uint32_t)end << 25));
         } else {
-          particle_finish(a, s, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
+          a->l_save[k] = 2;     // (status byte: 1 saved, 2 ended; 0 = not resolved yet, which only a sliced run ever sees)
+          if (p.npush < 2) {
+            // particle_finish! (transform, two bin look-ups, up to five tallies) is deferred like the zone-crossing
+            // tallies: a record on the wave's stack, tallied 64 at a time (a lane pushes at most two records per pass)
+            push_record(p, p.ig3, -1, (1u << 28) | ((uint32_t)end << 25));
+          } else {
+            particle_finish(a, s, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
+          }
         }
         cnt(a, MCS_IC_REASON0 + end);
         if (a->f_reason) {

@@ -96,6 +96,13 @@ class HipBackend:
     def set_launch(self, blocks: int = 0, threads: int = 0):
         self._chk(self.lib.mcs_set_launch(self.h, blocks, threads))
 
+    def set_tail_slicing(self, budget_trips: int):
+        """Sliced tail of run_pcut* (mcs_set_tail_slicing): 0 = one launch per pcut."""
+        self._chk(self.lib.mcs_set_tail_slicing(self.h, int(budget_trips)))
+
+    def last_launches(self) -> int:
+        return int(self.lib.mcs_last_launches(self.h))
+
     # -- per iteration / species
     def begin_iteration(self, i_iter):
         self._chk(self.lib.mcs_begin_iteration(self.h, i_iter))

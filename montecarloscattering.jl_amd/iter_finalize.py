@@ -232,9 +232,13 @@ def smooth_grid_par(prob, st: IterState, sm: SmoothingConfig, i_iter, pxx_flux, 
     Returns True if the tables of `prob` were changed."""
     P, cfg = prob.params, prob.cfg
     n = P.n_grid
-    if sm.increase_old_profile_weighting and i_iter != 1:        # smoothers.jl:95-98
-        st.prof_weight_fac *= 1.15 if i_iter < 6 else 1.5
-        st.prof_weight_fac = max(10.0, st.prof_weight_fac)
+    # smoothers.jl:95-98.  `prof_weight_fac` is a by-value Real all the way down (main_loops.jl:367 -> iter_finalize.jl:65 ->
+    # smoothers.jl:63) and nothing is returned: the damping rebinds a LOCAL, so every iteration starts again from the
+    # configured "old-profile-weight" -- w0 * 1.15 (iterations 2-5) or w0 * 1.5 (6 on), floored at 10; it does not compound.
+    w = sm.old_profile_weight
+    if sm.increase_old_profile_weighting and i_iter != 1:
+        w = max(10.0, w * (1.15 if i_iter < 6 else 1.5))
+    st.prof_weight_fac = w                                       # (what this iteration used: reporting only)
     if not sm.smooth_shocks:
         return False
     ux_new = new_velocity_profile(prob, st, sm, pxx_flux, energy_flux, q_px, q_en, P_par + P_perp)
@@ -244,7 +248,6 @@ def smooth_grid_par(prob, st: IterState, sm: SmoothingConfig, i_iter, pxx_flux, 
         sc = -(ux_new[i_trans - 1] - ux_new[n - 1]) / math.atan(prob.x_grid_rg[i_trans])
         for i in range(i_trans, P.i_shock + 1):
             ux_new[i - 1] = -math.atan(prob.x_grid_rg[i]) * sc + ux_new[n - 1]
-    w = st.prof_weight_fac
     ux_new = (ux_new + w * prob.ux[1:n + 1]) / (1 + w)           # smoothers.jl:305-307
     u0, g0 = P.u0, P.gam0
     n0 = float(sum(s.density * s.aa for s in cfg.species))

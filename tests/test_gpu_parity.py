@@ -78,6 +78,38 @@ def _lockstep(prob, N, n_pcuts, check_split=True, setup=None):
     return Io
 
 
+@pytest.mark.parametrize("budget", [1, 7, 60])
+def test_sliced_tail_is_bit_identical(budget):
+    """mcs_set_tail_slicing: waves export their live particles `budget` trips after the queue ran dry and later launches
+    resume them, spread over the chip's waves.  A history must not depend on how often it was suspended: end states,
+    saved arrays, split populations, integer tallies equal the oracle's bit for bit, through nine pcuts."""
+    N = 20000
+    prob = make_problem(N)
+    launches = []
+
+    def setup(be):
+        if hasattr(be, "set_tail_slicing"):
+            be.set_tail_slicing(budget)
+            orig = be.run_pcut
+            def run(ip, off, _o=orig, _b=be):
+                r = _o(ip, off); launches.append(_b.last_launches()); return r
+            be.run_pcut = run
+    _lockstep(prob, N, 9, setup=setup)
+    assert max(launches) > 1, launches            # the runs really were sliced
+
+
+def test_sliced_tail_general_kernel_mixed_species():
+    """The same through the general kernel: electrons with radiative losses, energy transfer, an oblique field."""
+    from golden_common import replay_and_compare as rc
+
+    def factory(prob):
+        be = hip_backend(prob)
+        be.set_tail_slicing(2)
+        return be
+    for name in ("mixed_n96", "electrons_crafted_n64"):
+        rc(factory, name, tally_rtol=TALLY_RTOL)
+
+
 def test_retro_walk_cap():
     """The reference's retro_time loop has no bound (src/prob_return.jl:257); here one walk ends after
     MCS_RETRO_CAP inner steps with i_reason 3 and a counter.  With the cap lowered to 4 steps many walks

@@ -110,6 +110,25 @@ def test_smooth_grid_par_matches_twin_on_real_tallies(variant):
         assert st2.prof_weight_fac == 10.0                                   # max(10, 2.5 * 1.15)
 
 
+def test_old_profile_weight_does_not_compound_over_iterations():
+    """`prof_weight_fac` is passed by value through main_loops -> iter_finalize -> smooth_grid_par and never returned
+    (src/main_loops.jl:367, src/iter_finalize.jl:65, src/smoothers.jl:63,95-98): the damping rebinds a local, so every
+    iteration starts again from "old-profile-weight" -- 1.15 w0 in iterations 2..5, 1.5 w0 from 6 on, floored at 10."""
+    prob, be, res, fin, ion = _one_iteration(N=600)
+    sm = itf.SmoothingConfig(old_profile_weight=9.0, increase_old_profile_weighting=True)
+    L = be.layout
+    st = itf.IterState.create(prob, sm, 8)
+    itf.set_Gamma_adiab_grid(st.Gamma_grid, 1, prob.x_grid_cm, st.Gamma2_RH, ion.P_psd_par, ion.P_psd_perp, ion.energy_density_psd)
+    pxx = np.round(L.view(res.tallies_f64, "pxx_flux"), 13); en = np.round(L.view(res.tallies_f64, "energy_flux"), 13)
+    used = {}
+    for i_iter in (1, 3, 7, 3, 2):
+        mine = copy.deepcopy(prob)
+        assert itf.smooth_grid_par(mine, st, sm, i_iter, pxx, en, 0.0, 0.0, ion.P_psd_par, ion.P_psd_perp)
+        used.setdefault(i_iter, []).append(st.prof_weight_fac)
+    assert used[1] == [9.0] and used[2] == [10.35] and used[7] == [13.5]
+    assert used[3] == [10.35, 10.35]          # the same after iteration 7 as before it: nothing is carried
+
+
 def test_classical_branch_matches_twin():
     """beta0 < 0.02 takes the non-relativistic equations (smoothers.jl:460-571; S2).  build_problem cannot make such a
     problem (calc_rRH's low-beta branch is broken in the reference, quirk G2), so the shock speed of a built problem is

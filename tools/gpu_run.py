@@ -23,8 +23,9 @@ hb.begin_species(1, 1, 1.0, 1.0, prob.pmax, 1.0, 1.0)
 hb.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
 hb.init_pop(inj, 0, inj.n_pts_use, inj.n_pts_use)
 ng = prob.n_grid; IC = m.capi.IC
-prev = 0; tot_ms = 0; tot_steps = 0
+prev = 0; tot_ms = 0; tot_steps = 0; tot_launches = 0
 import ctypes as ct
+hb.sync(); t_wall0 = time.perf_counter()
 for ip in range(1, NPC + 1):
     n = hb.pop_size()
     ns = hb.run_pcut(ip, 0)
@@ -33,7 +34,10 @@ for ip in range(1, NPC + 1):
     st = int(i64[ng + IC["STEPS_HELIX"]] + i64[ng + IC["STEPS_RETRO"]]); d = st - prev; prev = st
     retro = int(i64[ng + IC["STEPS_RETRO"]])
     ms = hb.last_kernel_ms(); tot_ms += ms; tot_steps += d
-    print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms rate={d/(ms*1e-3+1e-12):.3e} steps/s retro_cum={retro}", flush=True)
+    tot_launches += hb.last_launches()
+    print(f"pcut {ip:2d} n={n} saved={ns} steps={d} kernel={ms:.2f} ms launches={hb.last_launches()} rate={d/(ms*1e-3+1e-12):.3e} steps/s retro_cum={retro}", flush=True)
     if ns == 0: break
     hb.new_pcut(max(N // ns, 1))
-print(f"TOTAL steps={tot_steps} kernel_ms={tot_ms:.1f} rate={tot_steps/(tot_ms*1e-3):.3e} steps/s")
+hb.sync(); wall = (time.perf_counter() - t_wall0) * 1e3
+print(f"TOTAL steps={tot_steps} kernel_ms={tot_ms:.1f} wall_ms={wall:.1f} (incl. one tally read-back per pcut) launches={tot_launches} rate={tot_steps/(tot_ms*1e-3):.3e} steps/s "
+      f"MCS_TAIL_BUDGET={os.environ.get('MCS_TAIL_BUDGET', '0')}")
