@@ -706,16 +706,20 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
     HIPCHK(hipMemsetAsync(c->d_counters + 3, 0, sizeof(unsigned long long), c->stream));    // export counter
     a.strag_in = c->d_strag[round & 1]; a.strag_out = c->d_strag[(round + 1) & 1];
     a.n_resume = (long long)n_x; a.fresh_lo = n;
-    const long long waves = full * (threads / 64);
-    long long cm = ((long long)n_x + waves - 1) / waves;
-    if (cm >= 32) cm = 64;
+    // measured (profiles/r03_tau_vs_lanes.txt: 2048 particles, kernel time of 14 pcuts): 64 particles per wave 45.6 ms, 32: 38.1,
+    // 16: 35.6, 8: 33.4, 4: 31.6, 2 (one wave per SIMD): 31.7, 1 (two waves per SIMD): 37.9 -- so one wave per SIMD, as few
+    // particles per wave as that allows, and a dense launch when that would be more than 16
+    const long long waves1 = (long long)c->n_cu * (threads / 64);           // one wave per SIMD
+    long long cm = ((long long)n_x + waves1 - 1) / waves1;
+    if (cm > 16) cm = 64;
     a.claim_max = (int)cm;
     if (cm < 64) { a.defer_k = 1; a.wait_full = 0; a.tail_merge = 0; }
+    else { a.defer_k = c->defer_k > 64 - c->refill_min ? 64 - c->refill_min : c->defer_k; a.wait_full = c->park ? 1 : 0; a.tail_merge = c->tail_merge ? 1 : 0; }
     const long long per_block = (long long)(threads / 64) * cm;
     long long nb = ((long long)n_x + per_block - 1) / per_block;
     blocks = (int)(nb < full ? nb : full);
-    // one particle per wave and at most one wave per SIMD: nothing left to gain from another slice
-    a.budget_trips = ((long long)n_x <= (long long)c->n_cu * (threads / 64)) ? 0 : budget;
+    // few particles per wave already: nothing left to gain from another slice
+    a.budget_trips = cm <= 4 ? 0 : budget;
   }
   // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
   // independent count of the l_save flags next to the kernel's own n_saved counter, read back together
