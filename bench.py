@@ -105,6 +105,25 @@ def overlapped_leg(mcs, hip_backend, prob, be0, local, args):
             "steps": n, "note": "independent iterations (fixed shock profile) sharing the GPU; not the headline value"}
 
 
+def workload_label(args):
+    """What actually ran, built from the arguments: every kept bench line names its own workload."""
+    n = args.particles
+    size = f"{n:.0e}".replace("e+0", "e").replace("e+", "e") if n >= 1000 and n == float(f"{n:.0e}") else str(n)
+    if n == 1_000_000 and not args.smooth:
+        head = "BASELINE config[1]: "
+    elif n == 10_000_000 and args.smooth:
+        head = "BASELINE config[2] (evolving profile): "
+    elif n == 10_000_000:
+        head = "BASELINE config[2]'s population on a FIXED profile: "
+    else:
+        head = "non-headline size: "
+    profile = ("shock profile replaced after every iteration (smooth_grid_par; every zone crossing takes the frame transform)"
+               if args.smooth else "single unmodified gamma0=5 shock")
+    return (f"{head}{size} protons per GPU, {profile}, 45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration "
+            f"(init_pop, 45 x (transport + new_pcut), tally merge [{args.species_tallies} read-back per species], ion_finalize consumers, "
+            f"iter_finalize" + (" + profile update" if args.smooth else "") + ")")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +229,7 @@ def main():
     # HBM bytes per K1 launch: NOT measured by this process -- the committed result of the separate
     # `rocprofv3 --pmc` passes over this same command (tools/profile_bench.sh), labelled as such
     traffic, traffic_src = None, None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["hbm_bytes_per_launch"]
@@ -226,16 +245,13 @@ def main():
         value = steps_total / elapsed
         ach = local_steps * FLOP_PER_STEP / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         out = {
-            "metric": "particle-scatter steps/sec + wall-time per iter, 10^6 particles, 1->8 MI355X",
+            "metric": "particle-scatter steps/sec + wall-time per iter, 10^6 particles, 1->8 MI355X",      # (BASELINE.json's metric name, whatever --particles says: config.workload names what ran)
             "value": value, "unit": "particle-scatter steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: 1e6 protons per GPU, single unmodified gamma0=5 shock, "
-                                   "45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration "
-                                   "(init_pop, 45 x (transport + new_pcut), tally merge, ion_finalize consumers, iter_finalize"
-                                   + (", profile smoothing" if args.smooth else "") + ")",
+            "config": {"workload": workload_label(args),
                        "particles_per_gpu": args.particles, "particles_total": n_global, "species_tallies": args.species_tallies,
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 8 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},

@@ -182,7 +182,6 @@ __shared__ int S_nc[MCS_MAXNE];             // num_crossings staging
 __shared__ double S_evf[4][MCS_EV_F64][MCS_EV_CAP];
 __shared__ unsigned int S_evu[4][MCS_EV_CAP];
 __shared__ unsigned int S_evcur[4];         // per-wave stack height
-struct Lds {};                               // an empty handle: the tables are static LDS arrays, call sites pass it along
 
 // ---- particle state (registers) ---------------------------------------------------
 // The zone properties "of the current pass" (ux, uz, utot, gamma_sf, gamma_ef, sin/cos
@@ -352,7 +351,7 @@ __device__ __forceinline__ void transform_p_PS(double aa, double pb_pf, double p
 struct Mom { double ptot, pb, pperp, gam, phi; };
 
 // src/transformers.jl:523-607: zone io (old) -> zone in (new)
-__device__ MCS_COLD Mom transform_p_PSP(CK* a, Lds s, int io, int in, double r_pb, double r_pperp, double r_gam,
+__device__ MCS_COLD Mom transform_p_PSP(CK* a, int io, int in, double r_pb, double r_pperp, double r_gam,
                                             double r_phi) {
   const double aa = a->aa;
   const double ux_o = S_ux[io], uz_o = S_uz[io], ut_o = S_ut[io], gsf_o = S_gsf[io], bcos_o = S_bcos[io], bsin_o = S_bsin[io];
@@ -492,7 +491,7 @@ __device__ MCS_COLD void tcut_track(CK* a, int tcut_curr, double weight, double 
 // Tally part of all_flux! (src/all_flux.jl:84-161: transform, calculate_x_spec_spectra!,
 // F_stream!, FEB tracker), entered only when the zone changed (or i_grid <= i_grid_feb,
 // or x_spec detectors exist).  By-value arguments: nothing of the caller is forced to memory.
-__device__ MCS_COLD void flux_tally(CK* a, Lds s, double pb_pf, double p_perp, double ptot_pf, double gam_pf,
+__device__ MCS_COLD void flux_tally(CK* a, double pb_pf, double p_perp, double ptot_pf, double gam_pf,
                                         double phi, double weight, double x, double x_old, int i_grid, int i_grid_old,
                                         int ig3, bool inj) {
   const auto& P = a->P;
@@ -586,7 +585,7 @@ struct Retro {
 };
 
 // src/prob_return.jl:217-344 (with D1: the scattered pitch is kept)
-__device__ MCS_COLD Retro retro_time(CK* a, Lds s, Retro r, double prp, double weight, uint32_t k0, uint32_t k1) {
+__device__ MCS_COLD Retro retro_time(CK* a, Retro r, double prp, double weight, uint32_t k0, uint32_t k1) {
   const auto& P = a->P;
   const int ng = P.n_grid;
   const double aa = a->aa;
@@ -733,7 +732,7 @@ __device__ MCS_COLD Mom do_energy_transfer(CK* a, int i_grid, int i_grid_old, do
 // src/particle_finish.jl:46-107 (with D2).  Zone properties of zone ig3.
 // `off`/`val` (optional): the escape-spectrum tally is handed back instead of being added, so that the caller can
 // combine the lanes of a wave that hit the same bin (see drain_events)
-__device__ MCS_COLD void particle_finish(CK* a, Lds s, int i_reason, double pb_pf, double p_perp, double gam_pf,
+__device__ MCS_COLD void particle_finish(CK* a, int i_reason, double pb_pf, double p_perp, double gam_pf,
                                              double phi, double weight, int ig3, long long* off = nullptr, double* val = nullptr) {
   const double aa = a->aa;
   const double m = aa * MP_;
@@ -777,7 +776,7 @@ __device__ __forceinline__ void refresh_time(CK* a, const Hot& h, Pt& p) {
 
 // src/prob_return.jl:36-173, entered only when it has something to do (the caller has
 // already set i_return = 2 and filtered the no-op cases).
-__device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt, bool& capped) {
+__device__ __forceinline__ void prob_return_events(CK* a, const Hot& h, Rng& rng, Pt& p, int& i_return, bool& lose_pt, bool& capped) {
   const auto& P = a->P;
   const double aa = h.aa, u2 = h.u2, eta = h.eta, x_grid_stop = h.x_grid_stop;
   if (p.x < x_grid_stop) {
@@ -802,7 +801,7 @@ __device__ __forceinline__ void prob_return_events(CK* a, const Lds& s, const Ho
       r.ptot = p.ptot_pf; r.pb = p.pb_pf; r.pperp = p.p_perp; r.gam = p.gam_pf; r.phi = p.phi;
       r.gyro_denom = p.gyro_denom; r.acctime = p.acctime; r.tcut_next = tcut_next_of(a, h, p.tcut); r.tcut = p.tcut;
       r.n_retro = p.n_retro; r.rng_n = rng.n; r.lose_pt = false; r.capped = false;
-      r = retro_time(a, s, r, p.prp, p.weight, rng.k0, rng.k1);
+      r = retro_time(a, r, p.prp, p.weight, rng.k0, rng.k1);
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_denom = r.gyro_denom; p.acctime = r.acctime; p.tcut = r.tcut;
       p.n_retro = r.n_retro; rng.n = r.rng_n; lose_pt = r.lose_pt; capped = r.capped;
@@ -839,7 +838,7 @@ __device__ __forceinline__ void load_zone_edges(Pt& p) {
 }
 
 // load a particle and run the prologue of particle_loop (src/particle_loop.jl:44-153)
-__device__ __forceinline__ void load_particle(CK* a, const Lds& s, const Hot& h, long long k, Pt& p, Rng& rng) {
+__device__ __forceinline__ void load_particle(CK* a, const Hot& h, long long k, Pt& p, Rng& rng) {
   p.weight = a->in.weight[k];
   p.ptot_pf = a->in.ptot_pf[k];
   p.pb_pf = a->in.pb_pf[k];
@@ -1075,7 +1074,7 @@ __device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, 
 
 // Everything the last move triggered (the tail of Code Block 2 and Code Block 3's all_flux /
 // downstream_test / prob_return part, particle_loop.jl:352-358, 409-499).  Returns the end code or -1.
-__device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng& rng, Pt& p, double phi_old) {
+__device__ __forceinline__ int slow_post(CK* a, const Hot& h, Rng& rng, Pt& p, double phi_old) {
   const double aa = h.aa;
   const int ig3 = p.ig3;
   const int i_grid_before = p.i_grid;
@@ -1147,7 +1146,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Lds& s, const Hot& h, Rng&
   }
   bool lose_pt = false, capped = false;
   TTG_MARK(43);
-  if (do_prob_ret) prob_return_events(a, s, h, rng, p, i_return, lose_pt, capped);
+  if (do_prob_ret) prob_return_events(a, h, rng, p, i_return, lose_pt, capped);
   TTG_MARK(44);
   if (i_return == 0) {
     if (capped) return 3;      // MCS_RETRO_CAP: ends like an aged-out particle -- nothing added to the downstream sums (as the oracle)
@@ -1181,7 +1180,7 @@ __device__ __forceinline__ void refresh_move(CK* a, const Hot& h, Pt& p) {
 // Everything before the next scatter (head of the loop body and of Code Block 3,
 // particle_loop.jl:154-326, 361-385).  `t_clock` is the time step of the previous move, which the
 // clock of this pass still uses (particle_loop.jl:350 precedes :400).  Returns the end code or -1.
-__device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock) {
+__device__ __forceinline__ int slow_pre(CK* a, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock) {
   const double aa = h.aa;
   if (p.helix >= MCS_HELIX_CAP) {            // the pass about to start would be number cap+1: quirk Q5
     p.helix += 1;
@@ -1204,7 +1203,7 @@ __device__ __forceinline__ int slow_pre(CK* a, const Lds& s, const Hot& h, const
     }
     if (gd != p.gyro_denom) { p.gyro_denom = gd; f |= F_RS | F_RM; }
     if (ig != io && S_ux[ig] != S_ux[io]) {  // same u_x => no frame transform (particle_loop.jl:214)
-      const Mom r = transform_p_PSP(a, s, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
+      const Mom r = transform_p_PSP(a, io, ig, p.pb_pf, p.p_perp, p.gam_pf, p.phi);
       p.ptot_pf = r.ptot; p.pb_pf = r.pb; p.p_perp = r.pperp; p.gam_pf = r.gam; p.phi = r.phi;
       p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
       p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
@@ -1339,7 +1338,7 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
 }  // namespace
 
 // Pop up to 64 records from this wave's stack and tally them, one per lane (convergent code).
-__device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, unsigned lane, bool all) {
+__device__ __forceinline__ void drain_events(CK* a, unsigned wv, unsigned lane, bool all) {
   unsigned cnt = S_evcur[wv];
   while (cnt >= 64u || (all && cnt > 0u)) {
     const unsigned take = cnt < 64u ? cnt : 64u;
@@ -1349,10 +1348,10 @@ __device__ __forceinline__ void drain_events(CK* a, const Lds& s, unsigned wv, u
       const unsigned e = base + lane;
       const uint32_t u = S_evu[wv][e];
       if (u >> 28) {     // a finished particle (particle_finish!): reason in bits 25-27
-        particle_finish(a, s, (int)((u >> 25) & 7u), S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][3][e], S_evf[wv][4][e],
+        particle_finish(a, (int)((u >> 25) & 7u), S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][3][e], S_evf[wv][4][e],
                         S_evf[wv][5][e], (int)((u >> 16) & 0xffu), &foff, &fval);
       } else {
-        flux_tally(a, s, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
+        flux_tally(a, S_evf[wv][0][e], S_evf[wv][1][e], S_evf[wv][2][e], S_evf[wv][3][e], S_evf[wv][4][e], S_evf[wv][5][e],
                    S_evf[wv][6][e], S_evf[wv][7][e], (int)(u & 0xffu), (int)((u >> 8) & 0xffu), (int)((u >> 16) & 0xffu),
                    ((u >> 24) & 1u) != 0u);
       }
@@ -1548,7 +1547,6 @@ template <bool PLAIN>
 __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
-  Lds s;
   block_prologue(a);
   __syncthreads();
 
@@ -1694,7 +1692,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     ++mtick;
     // (bitwise | on purpose: one scalar branch, not a chain of short-circuit branches)
     if (MCS_UNLIKELY(((ev_pending >= 64u) | ((unsigned)n_idle + n_wait >= refill_at) | ((mtick & mpoll_mask) == 0u)) != 0)) {
-      if (ev_pending >= 64u) { drain_events(a, s, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
+      if (ev_pending >= 64u) { drain_events(a, wv, lane, false); ev_pending &= 63u; PROF_ADD(3, 1); }
       // the batch is complete: the waiting lanes run their Code Blocks in the coming pass, with the new particles
       if (n_wait > 0u && (exhausted || (unsigned)n_idle + n_wait >= refill_min)) {
         if (waitl) p.flags = (p.flags & ~F_WAIT) | F_NOPARK;
@@ -1727,7 +1725,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           const unsigned long long idx = base + (unsigned long long)rank;
           if (rank < nidle && idx >= n_resume && idx < n) {
             k = a->fresh_lo + (long long)(idx - n_resume);
-            load_particle(a, s, h, k, p, rng);
+            load_particle(a, h, k, p, rng);
             act = -1; evw = 0; rb = 0u - 256u;
             // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
             // every outstanding store and no-return tally atomic)
@@ -1738,7 +1736,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         // stack, used as a mailbox exactly as in the tail consolidation (pending records are tallied first); up to
         // MCS_MB_SLOTS at a time.  (Through LDS because 36 global loads per lane in this loop cost ~100 spilled registers.)
         if (!exhausted && __builtin_amdgcn_readfirstlane(base < n_resume ? 1 : 0)) {
-          drain_events(a, s, wv, lane, true); ev_pending = 0u;
+          drain_events(a, wv, lane, true); ev_pending = 0u;
           const unsigned long long left = n_resume - base;
           const unsigned cnt_r = (unsigned)(left < (unsigned long long)nidle ? left : (unsigned long long)nidle);
           const unsigned rank = below(idle);
@@ -1801,7 +1799,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;
           } else if (nlive <= MCS_MB_SLOTS && nlive <= room) {
             // donor: tally the pending records (the mailbox is their stack), write the particles, hand over
-            drain_events(a, s, wv, lane, true); ev_pending = 0u;
+            drain_events(a, wv, lane, true); ev_pending = 0u;
             if (active) mb_store(wv, below(__builtin_amdgcn_ballot_w64(active)), p, rng, k, evw, phi_prev);
             rb = rng.n - 256u;            // the mailbox has overwritten this wave's ring (it may have to carry on alone)
             unsigned st = 2u;
@@ -1827,7 +1825,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           if ((int)lane == leader) base = atomicAdd(a->strag_count, (unsigned long long)nlive);
           base = __shfl(base, leader);
           // (through the record stack as a mailbox, MCS_MB_SLOTS particles at a time: see the import above)
-          drain_events(a, s, wv, lane, true); ev_pending = 0u;
+          drain_events(a, wv, lane, true); ev_pending = 0u;
           const unsigned rank = below(am_x);
           double* const box = &S_evf[wv][0][0];
           for (unsigned b0 = 0; b0 < (unsigned)nlive; b0 += MCS_MB_SLOTS) {
@@ -1982,7 +1980,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         TT_MARK(20);
         bool pend = post_pending;
         for (;;) {
-          if (pend) { TTG_START(); end = slow_post(a, s, h, rng, p, phi_prev); if (end >= 0) break; }
+          if (pend) { TTG_START(); end = slow_post(a, h, rng, p, phi_prev); if (end >= 0) break; }
           if (!(p.flags & F_B1)) break;
           pend = block1_step(a, h, p, phi_prev, end);
           if (end >= 0) break;
@@ -1990,7 +1988,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           t_clock = p.t_step;
         }
         TT_MARK(17);
-        if (end < 0) end = slow_pre(a, s, h, kc, rng, p, t_clock);
+        if (end < 0) end = slow_pre(a, h, kc, rng, p, t_clock);
         TT_MARK(18);
       }
       if (end >= 0) {
@@ -2015,7 +2013,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             // tallies: a record on the wave's stack, tallied 64 at a time (a lane pushes at most two records per pass)
             push_record(p, p.ig3, -1, (1u << 28) | ((uint32_t)end << 25));
           } else {
-            particle_finish(a, s, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
+            particle_finish(a, end, p.pb_pf, p.p_perp, p.gam_pf, p.phi, p.weight, p.ig3);
           }
         }
         cnt(a, MCS_IC_REASON0 + end);
@@ -2133,7 +2131,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     g_wave[gw__][7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); }   // HW_REG_XCC_ID
 #endif
   // ---- the wave's remaining tally records, then the LDS staging
-  drain_events(a, s, wv, lane, true);
+  drain_events(a, wv, lane, true);
   __syncthreads();
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF && S_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], S_prof[threadIdx.x]);

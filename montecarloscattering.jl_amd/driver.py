@@ -131,7 +131,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         max_pcuts: Optional[int] = None, on_species_end: Optional[Callable] = None,
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
-        first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True) -> RunResult:
+        first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True,
+        before_pcut: Optional[Callable] = None) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -149,6 +150,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     iter_finalize reads) and the int64 tallies; psd / therm_sf / therm_pf stay on the device, where their consumers run (K4),
     and are fetched once, after the last species of the last iteration (RunResult.tallies_f64 is then complete; with
     final_full_read = False not even then -- run_overlapped fetches every context's buffer once, at the very end).
+    before_pcut(i_iter, i_ion, i_pcut): called before every transport launch (run_overlapped sets the launch geometry there).
     first_iter / iter_state: run iterations first_iter .. first_iter + n_itrs - 1 (the iteration number enters the
     RNG keys and indexes the per-iteration tallies), carrying the iter_finalize state of an earlier call
     (RunResult.iter_state) -- lets a caller step through the loop one iteration at a time.
@@ -174,7 +176,13 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     local_steps = []    # (i_iter, i_ion, steps this rank's kernels made for that species)
     from .capi import IC as _IC
     i_h, i_r = P.n_grid + _IC["STEPS_HELIX"], P.n_grid + _IC["STEPS_RETRO"]
-    steps_seen = 0      # the step counters are never reset: this rank's running total
+    # the step counters are never reset: this rank's running total.  A context that has run before (run() called again with
+    # first_iter / iter_state, the documented way to step through the loop) starts from what its counters hold now.
+    if dev_t is not None:
+        steps_seen = int(dev_t[1][i_h].item() + dev_t[1][i_r].item())
+    else:
+        _, _i0 = backend.read_tallies_light() if hasattr(backend, "read_tallies_light") else backend.read_tallies()
+        steps_seen = int(_i0[i_h] + _i0[i_r])
     iter_finals = []
     if smoothing is not None:
         finalize = True
@@ -232,6 +240,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             n_use_global = n_total
             for i_pcut in range(1, n_pcuts + 1):
                 t0 = time.perf_counter()
+                if before_pcut is not None:
+                    before_pcut(i_iter, i_ion, i_pcut)
                 if gidx is not None:
                     n_saved_local = backend.run_pcut_indexed(i_pcut, gidx)
                 else:
@@ -402,7 +412,7 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
     if blocks_per_launch is None and K > 1 and hasattr(backends[0], "num_cus"):
         blocks_per_launch = max(2 * backends[0].num_cus() // K, 1)
 
-    state = {"busy": 0, "started": 0}
+    state = {"busy": 0}
     state_lock = threading.Lock()
 
     def one(i_iter):
@@ -410,18 +420,24 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
         with locks[k]:                       # a context carries one iteration at a time
             be = backends[k]
             with state_lock:
-                state["started"] += 1
-                # the last iteration of an odd count has the chip to itself: the automatic geometry again
-                alone = state["busy"] == 0 and state["started"] == n_itrs
                 state["busy"] += 1
-            if blocks_per_launch and K > 1 and hasattr(be, "set_launch"):
-                be.set_launch(0 if alone else int(blocks_per_launch), 0 if alone else 256)
+            geo = blocks_per_launch and K > 1 and hasattr(be, "set_launch")
+
+            def geometry(*_):
+                # decided before EVERY launch: an iteration that is alone on the chip (the last one of an odd count, once its
+                # neighbour has finished) gets the automatic full-chip geometry back
+                if geo:
+                    alone = state["busy"] <= 1
+                    be.set_launch(0 if alone else int(blocks_per_launch), 0 if alone else 256)
             try:
-                res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False)
+                res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False,
+                          before_pcut=geometry)
                 ion_fin = consumers.ion_finalize(prob, be, len(cfg.species))     # K4, before the context is reused
             finally:
                 with state_lock:
                     state["busy"] -= 1
+                if geo:
+                    be.set_launch(0, 0)      # back to the automatic geometry, also when the iteration raised
         return k, res, ion_fin
 
     stats, per_species, iter_finals, local_steps = [], [], [], []
@@ -445,10 +461,6 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
             if on_iteration_end is not None:
                 on_iteration_end(i_iter)
     # the state after the last iteration: its context's buffer, with the never-reset tallies summed over the contexts
-    if blocks_per_launch and K > 1:
-        for be in backends:
-            if hasattr(be, "set_launch"):
-                be.set_launch(0, 0)               # back to the automatic geometry
     k_last = (n_itrs - 1) % K
     f, i64 = backends[k_last].read_tallies()              # the only time the three histograms cross to the host
     for k in last:

@@ -21,8 +21,13 @@ TALLY_RTOL = 1e-11
 # Arrays whose entries are sums of 1e7..1e8 terms at this size: the three flux vectors (signed terms per zone: upstream-
 # and downstream-going crossings cancel to a tenth of their gross sum) and the per-species / per-time-cut / per-momentum-
 # bin accumulators (esc_flux: 1.6e7 IDENTICAL weights, whose rounding errors do not average out but add up along whatever
-# order the adds take -- one serial sum in the oracle, per-block partial sums in LDS on the GPU).  Measured 1.5e-11 and
-# 2.7e-11; bound 1e-10.  (The reference rounds its fluxes to 13 digits for the same reason, src/iter_finalize.jl:46-54.)
+# order the adds take -- one serial sum in the oracle, per-block partial sums in LDS on the GPU).
+# A-priori bound, not a fitted one: a sum of n non-negative fp64 terms differs between two summation orders by at most
+# ~n * 2^-53 of the sum (each add rounds by <= half an ulp of the running total); n = 1.6e7 gives 1.8e-9, and for the flux
+# vectors the cancellation multiplies it by ten.  The bound used, 1e-10, is TIGHTER than that worst case (rounding errors of
+# unequal terms mostly average out: measured 1.5e-11 .. 2.7e-11); 1e-11 holds for every array that sums < 1e6 terms per
+# entry.  A compensated reference sum would not tighten it: the GPU's own order-dependent rounding is the same size.
+# (The reference rounds its fluxes to 13 digits for the same reason, src/iter_finalize.jl:46-54.)
 LONG_SUM_RTOL = 1e-10
 LONG_SUMS = ("pxx_flux", "pxz_flux", "energy_flux", "esc_flux", "px_esc_feb", "energy_esc_feb", "esc_energy_eff", "esc_num_eff",
              "weight_coupled", "spectra_coupled_val", "scalars")
