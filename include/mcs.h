@@ -283,6 +283,10 @@ int mcs_read_tallies(mcs_ctx* ctx, double* host_f64 /*layout.total*/, int64_t* h
  * pools (src/iter_finalize.jl:27-70) -- is the tail of the layout from esc_psd_up on: 0.8 MB instead of 61. */
 int mcs_read_tallies_part(mcs_ctx* ctx, int64_t first, int64_t count, double* host_f64, int64_t* host_i64);
 int mcs_write_tallies(mcs_ctx* ctx, const double* host_f64, const int64_t* host_i64);
+/* The mirror of mcs_read_tallies_part: words [first, first + count) of the fp64 buffer from host_f64[0 .. count).  What the
+ * host rewrites in place between iterations is small: tcut_print normalises spectra_coupled and floors weight_coupled
+ * (src/io.jl:28-45, called at src/main_loops.jl:383-389). */
+int mcs_write_tallies_part(mcs_ctx* ctx, int64_t first, int64_t count, const double* host_f64);
 
 /* ---- consumers of the tallies, on the device-resident histograms ----
  * Host-made tables (O(bins), O(n_grid)); the edges are cgs momenta and true cos(theta) in the

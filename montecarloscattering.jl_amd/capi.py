@@ -229,6 +229,7 @@ def load_library() -> ct.CDLL:
         "mcs_run_pcut_host": (i32, [vp, i32, i64, i64, soa_p, soa_p, c_uint8_p, c_int64_p]),
         "mcs_read_tallies": (i32, [vp, c_double_p, c_int64_p]),
         "mcs_read_tallies_part": (i32, [vp, i64, i64, c_double_p, c_int64_p]),
+        "mcs_write_tallies_part": (i32, [vp, i64, i64, c_double_p]),
         "mcs_num_cus": (i32, [vp]),
         "mcs_write_tallies": (i32, [vp, c_double_p, c_int64_p]),
         "mcs_eval_fn": (i32, [vp, i32, i64, c_double_p, c_double_p, c_double_p]),
@@ -257,5 +258,5 @@ EXPORTED_SYMBOLS = [
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
     "mcs_run_pcut_strided", "mcs_run_pcut_indexed", "mcs_saved_gidx", "mcs_init_pop_binned_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
-    "mcs_set_tail_slicing", "mcs_last_launches",
+    "mcs_set_tail_slicing", "mcs_last_launches", "mcs_write_tallies_part",
 ]

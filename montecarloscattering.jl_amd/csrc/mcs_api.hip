@@ -822,6 +822,14 @@ int mcs_read_tallies_part(mcs_ctx* c, int64_t first, int64_t count, double* host
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
+int mcs_write_tallies_part(mcs_ctx* c, int64_t first, int64_t count, const double* host_f64) {
+  HIPCHK(hipSetDevice(c->device));
+  if (first < 0 || count < 0 || first + count > c->L.total || (count > 0 && !host_f64)) return fail("mcs_write_tallies_part: range outside the tally buffer");
+  if (fold_replicas(c)) return 1;
+  if (count > 0) HIPCHK(hipMemcpyAsync(c->d_T + first, host_f64, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
 int mcs_write_tallies(mcs_ctx* c, const double* host_f64, const int64_t* host_i64) {
   HIPCHK(hipSetDevice(c->device));
   if (fold_replicas(c)) return 1;

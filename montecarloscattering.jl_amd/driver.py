@@ -132,7 +132,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
         first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True,
-        before_pcut: Optional[Callable] = None) -> RunResult:
+        before_pcut: Optional[Callable] = None, tcut_print: bool = False) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -150,6 +150,11 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     iter_finalize reads) and the int64 tallies; psd / therm_sf / therm_pf stay on the device, where their consumers run (K4),
     and are fetched once, after the last species of the last iteration (RunResult.tallies_f64 is then complete; with
     final_full_read = False not even then -- run_overlapped fetches every context's buffer once, at the very end).
+    tcut_print: replicate the in-place rewrite the reference's `tcut_print` makes at the end of every iteration when time-cut
+    tracking is on (src/io.jl:28-45, src/main_loops.jl:383-389): weight_coupled floored, every coupled spectrum normalised
+    to a total of 1 and floored -- on the merged tallies, written back to the device (rank 0), so that the next iteration
+    accumulates on top of it exactly as the reference does.  Off by default: the tallies then stay plain sums over the
+    iterations, which is what the parity fixtures and the overlapped run compare.
     before_pcut(i_iter, i_ion, i_pcut): called before every transport launch (run_overlapped sets the launch geometry there).
     first_iter / iter_state: run iterations first_iter .. first_iter + n_itrs - 1 (the iteration number enters the
     RNG keys and indexes the per-iteration tallies), carrying the iter_finalize state of an earlier call
@@ -365,8 +370,16 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 itf.populate_eps_target(prob)        # src/main_loops.jl:76-81, top of the next iteration
                 backend.set_grid(prob)
                 backend.set_cuts(prob)
-            if on_iteration_end is not None:
-                on_iteration_end(i_iter)
+        if tcut_print and P.do_tcuts and is_root:
+            # (after iter_finalize, as at src/main_loops.jl:363-389; G_f is the merged buffer of the last species, which holds the
+            # coupled arrays of every species -- they are per-ion slices of one array)
+            from . import iter_finalize as _itf
+            wc, sc = L.view(G_f, "weight_coupled"), L.view(G_f, "spectra_coupled")
+            _itf.tcut_print(wc, sc, len(prob.tcuts), P.num_psd_mom_bins)
+            backend.write_tally("weight_coupled", wc)
+            backend.write_tally("spectra_coupled", sc)
+        if on_iteration_end is not None:
+            on_iteration_end(i_iter)
 
     ng = P.n_grid
     from .capi import IC

@@ -258,6 +258,12 @@ class HipBackend:
         i = np.ascontiguousarray(i, dtype=np.int64)
         self._chk(self.lib.mcs_write_tallies(self.h, _dp(f), i.ctypes.data_as(c_int64_p)))
 
+    def write_tally(self, name: str, arr):
+        """One named array of the layout back into the device buffer (mcs_write_tallies_part)."""
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        assert a.size == int(np.prod(self.layout.shapes[name]))
+        self._chk(self.lib.mcs_write_tallies_part(self.h, int(self.layout.offsets[name]), a.size, _dp(a)))
+
     # -- consumers of the tallies (K4)
     def dndp_cr(self, tabs):
         """get_dNdp_cr + CR normalisation on the resident psd -> ([3][n_grid][nmom+2], diag[2])."""

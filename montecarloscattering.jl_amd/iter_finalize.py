@@ -279,6 +279,32 @@ def populate_eps_target(prob):
     return prob.eps_target
 
 
+def tcut_print(weight_coupled, spectra_coupled, n_tcuts: int, num_psd_mom_bins: int):
+    """The side effect of `tcut_print` (src/io.jl:28-45), which main_loops calls at the end of EVERY iteration when time-cut
+    tracking is on (src/main_loops.jl:383-389) -- the printing itself is commented out there, the in-place rewrite is not:
+      weight_coupled[tcut, ion] < 1e-60            -> 1e-99
+      sum(spectra_coupled[:, tcut, ion]) > 1e-99   -> the spectrum is divided by that sum (over all 0:psd_max entries)
+      spectra_coupled[0:num_psd_mom_bins, tcut, ion] < 1e-60 -> 1e-99
+    for tcut = 1..n_tcuts and every ion.  spectra_coupled is never reset, so from the second iteration on the
+    kernel adds raw weights on top of a spectrum normalised to 1: replicated as written.
+    weight_coupled: [n_ions][100], spectra_coupled: [n_ions][100][201] (C order; python index = Julia index - 1 for tcut and
+    ion, equal for the momentum bin), modified in place."""
+    n_ions = weight_coupled.shape[0]
+    for ion in range(n_ions):
+        for tc in range(n_tcuts):
+            if weight_coupled[ion, tc] < 1.0e-60:
+                weight_coupled[ion, tc] = 1.0e-99
+            sp = spectra_coupled[ion, tc]
+            tot = 0.0
+            for v in sp:                     # Julia's sum over a 201-element slice is a plain left-to-right loop below
+                tot += v                     # its pairwise block size (1024): the same order here
+            if tot > 1.0e-99:
+                sp /= tot
+            head = sp[:num_psd_mom_bins + 1]
+            head[head < 1.0e-60] = 1.0e-99
+    return weight_coupled, spectra_coupled
+
+
 @dataclasses.dataclass
 class IterFinal:
     q_esc_cal_px: float

@@ -203,4 +203,22 @@ int orc_smooth_grid_par(int n_grid, int i_shock, const double* x_grid_rg, double
   return 0;
 }
 
+// tcut_print's in-place rewrite (src/io.jl:28-45): wc [n_ions][100], sc [n_ions][100][201], C order.
+int orc_tcut_print(double* wc, double* sc, int n_ions, int n_tcuts, int num_psd_mom_bins) {
+  const int NA = 100, PM = 201;
+  for (int ion = 0; ion < n_ions; ++ion)
+    for (int tc = 0; tc < n_tcuts; ++tc) {
+      double& w = wc[(size_t)ion * NA + tc];
+      if (w < 1.0e-60) w = 1.0e-99;
+      double* sp = sc + ((size_t)ion * NA + tc) * PM;
+      double tot = 0.0;
+      for (int i = 0; i < PM; ++i) tot += sp[i];
+      if (tot > 1.0e-99)
+        for (int i = 0; i < PM; ++i) sp[i] = sp[i] / tot;
+      for (int i = 0; i <= num_psd_mom_bins; ++i)
+        if (sp[i] < 1.0e-60) sp[i] = 1.0e-99;
+    }
+  return 0;
+}
+
 }  // extern "C"

@@ -65,6 +65,7 @@ def load(math: str = "det", capi=None):
         "orc_upstream_fluxes": (i32, [i32, dp, dp, dp, dbl, dbl, dbl, dbl, dbl, dp]),
         "orc_q_esc_calcs": (i32, [dbl, dbl, dbl, i32, dp, dp, dp, dbl, dbl, dbl, dbl, dbl, dbl, dp]),
         "orc_set_gamma_grid": (i32, [dp, i32, i32, dp, dbl, dp, dp, dp]),
+        "orc_tcut_print": (i32, [dp, dp, i32, i32, i32]),
         "orc_smooth_grid_par": (i32, [i32, i32, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp] + [dbl] * 16 + [dp]),
     }
     if capi is not None:
@@ -252,6 +253,11 @@ class OracleBackend:
         f = np.ascontiguousarray(f, dtype=np.float64)
         i = np.ascontiguousarray(i, dtype=np.int64)
         self._chk(self.lib.orc_write_tallies(self.h, _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64))))
+
+    def write_tally(self, name, arr):
+        f, i = self.read_tallies()
+        self.layout.view(f, name)[...] = np.asarray(arr).reshape(self.layout.shapes[name])
+        self.write_tallies(f, i)
 
     # -- consumers of the tallies (oracle/mcs_consumers.cpp)
     def dndp_cr(self, tabs, tallies=None):

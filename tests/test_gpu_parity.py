@@ -110,6 +110,24 @@ def test_sliced_tail_general_kernel_mixed_species():
         rc(factory, name, tally_rtol=TALLY_RTOL)
 
 
+def test_tcut_print_rewrite_on_device_buffers():
+    """driver.run(tcut_print=True): the per-iteration rewrite of weight_coupled / spectra_coupled (src/io.jl:28-45) goes back
+    into the device buffer (mcs_write_tallies_part), so iteration 2 accumulates on top of the normalised spectra -- GPU and
+    oracle through the same driver, two iterations."""
+    N, npc = 4000, 12
+    pg, po = make_problem(N), make_problem(N)
+    hb, ob = hip_backend(pg), oracle_backend(po, nthreads=8)
+    rg = mcs.driver.run(pg, hb, None, n_itrs=2, max_pcuts=npc, tcut_print=True)
+    ro = mcs.driver.run(po, ob, None, n_itrs=2, max_pcuts=npc, tcut_print=True)
+    assert np.array_equal(rg.tallies_i64, ro.tallies_i64)
+    assert_tallies_close(hb.layout, rg.tallies_f64, ro.tallies_f64, TALLY_RTOL)
+    sc = hb.layout.view(rg.tallies_f64, "spectra_coupled")[0, :len(pg.tcuts)]
+    assert sc.sum() > 1.5 and np.all(sc[:, :pg.params.num_psd_mom_bins + 1] >= 1e-99)      # normalised spectra, floored
+    Tg, _ = hb.read_tallies()
+    assert np.array_equal(hb.layout.view(Tg, "spectra_coupled"), hb.layout.view(rg.tallies_f64, "spectra_coupled"))   # the device holds it
+    hb.destroy()
+
+
 def test_retro_walk_cap():
     """The reference's retro_time loop has no bound (src/prob_return.jl:257); here one walk ends after
     MCS_RETRO_CAP inner steps with i_reason 3 and a counter.  With the cap lowered to 4 steps many walks

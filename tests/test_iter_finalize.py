@@ -129,6 +129,42 @@ def test_old_profile_weight_does_not_compound_over_iterations():
     assert used[3] == [10.35, 10.35]          # the same after iteration 7 as before it: nothing is carried
 
 
+def test_tcut_print_normalisation_over_iterations():
+    """driver.run(tcut_print=True) replicates the in-place rewrite of src/io.jl:28-45 at the end of every iteration
+    (src/main_loops.jl:383-389): spectra_coupled, which is never reset, is normalised to 1 per (tcut, ion) and floored; the
+    next iteration adds raw weights on top.  Checked against the C++ twin applied to the raw per-iteration increments."""
+    N, npc = 1200, 12
+    lib = orc.load("det", mcs.capi)
+    raw = []
+    prob = make_problem(N); be = oracle_backend(prob, nthreads=8)
+    L = be.layout
+    mcs.driver.run(prob, be, None, n_itrs=2, max_pcuts=npc,
+                   on_iteration_end=lambda it: raw.append(tuple(L.view(be.read_tallies()[0], k).copy() for k in ("weight_coupled", "spectra_coupled"))))
+    (w1, s1), (w2, s2) = raw
+    assert s1.sum() > 0 and (s2 - s1).sum() > 0                  # both iterations tallied coupled spectra
+    nt, nm = len(prob.tcuts), prob.params.num_psd_mom_bins
+
+    def twin(w, s):
+        w, s = np.ascontiguousarray(w).copy(), np.ascontiguousarray(s).copy()
+        assert lib.orc_tcut_print(_p(w.ravel()), _p(s.ravel()), w.shape[0], nt, nm) == 0
+        return w, s
+    e_w1, e_s1 = twin(w1, s1)
+    e_w2, e_s2 = twin(w2, e_s1 + (s2 - s1))                      # weight_coupled is reset every iteration, spectra_coupled never
+    prob = make_problem(N); be = oracle_backend(prob, nthreads=8)
+    got = []
+    res = mcs.driver.run(prob, be, None, n_itrs=2, max_pcuts=npc, tcut_print=True,
+                         on_iteration_end=lambda it: got.append(tuple(L.view(be.read_tallies()[0], k).copy() for k in ("weight_coupled", "spectra_coupled"))))
+    (g_w1, g_s1), (g_w2, g_s2) = got
+    assert np.array_equal(g_w1, e_w1) and np.allclose(g_s1, e_s1, rtol=1e-13, atol=0)
+    assert np.allclose(g_w2, e_w2, rtol=1e-13, atol=0) and np.allclose(g_s2, e_s2, rtol=1e-12, atol=0)
+    assert np.array_equal(L.view(res.tallies_f64, "spectra_coupled"), g_s2)      # the result carries the rewritten arrays
+    tot = g_s1[0, :nt].sum(axis=1)
+    hit = s1[0, :nt].sum(axis=1) > 0
+    assert hit.any() and np.allclose(tot[hit], 1.0, rtol=1e-12)                  # every spectrum that was hit sums to 1
+    assert np.all(g_s1[0, :nt, :nm + 1] >= 1.0e-99) and np.all(g_w1[0, :nt] >= 1.0e-99)
+    assert np.all(g_s1[0, nt:] == 0)                                             # time cuts beyond n_tcuts are not touched
+
+
 def test_classical_branch_matches_twin():
     """beta0 < 0.02 takes the non-relativistic equations (smoothers.jl:460-571; S2).  build_problem cannot make such a
     problem (calc_rRH's low-beta branch is broken in the reference, quirk G2), so the shock speed of a built problem is
