@@ -49,7 +49,7 @@ class PcutStat:
     n_saved: int            # global
     i_mult: int
     n_use_max: int          # largest local population of this pcut over the ranks (load balance: max/mean)
-    split: str              # how the NEXT population was built: "local" | "gather" | "-" (last pcut)
+    split: str              # how the NEXT population was built: "local" | "gather" | "identity" (all saved, i_mult 1: nothing moves) | "-" (last pcut)
     kernel_ms: float        # local kernel time (HIP events), nan for CPU backends
     wall_ms: float
 
@@ -272,8 +272,15 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                           f"wall={wall:.1f} ms", flush=True)
                 if n_saved == 0:
                     break
+                identity = multi and n_saved == n_use_global and i_mult == 1
                 n_use_global = n_saved * i_mult
-                if not multi:
+                if identity:
+                    # everybody was saved and nobody is replicated (the first pcuts of a species): the saved particles' positions
+                    # in the global order ARE their indices, so every rank's children keep the global indices their parents had
+                    # -- no index column to exchange, no particle to move; the shard description (first / stride / gidx) stands
+                    backend.new_pcut(1)
+                    stats[-1].split = "identity"
+                elif not multi:
                     backend.new_pcut(i_mult)                     # one process: the shard stays 0, 1, 2, ...
                     n_local = n_use_global
                 elif local_ok:

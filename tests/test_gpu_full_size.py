@@ -73,25 +73,26 @@ def test_config1_full_size_vs_oracle_fixture():
     print(f"config[1] at 1e6: {len(fix.files) - 3} binned arrays within {TALLY_RTOL}; worst {worst[0]} {worst[1]:.2e}; {fix['meta']}")
 
 
-def _property_run(N, n_prefix=4096, prefix_pcuts=5):
+def _property_run(N, n_prefix=4096, prefix_pcuts=5, prob=None, i_iter=1):
     """One species through every pcut it reaches.  Per pcut: (i) every particle ends in exactly one way and the
     saved flags are the reason-0 particles; (ii) the counters' exits equal the particles that ended; (iii) the first
     n_prefix particles equal the oracle's bit for bit while the prefix stays aligned (pcuts 1-4 save everybody);
     (iv) the split population is i_mult copies of each saved particle, in order, with weight / i_mult.  At the end:
     weight is conserved through all splits, the upstream-escape tallies carry exactly the weight of the particles
     that escaped upstream (LDS-staged and wave-reduced tallies at full size), no zone search failed."""
-    prob = make_problem(N)
+    prob = make_problem(N) if prob is None else prob      # (a caller's problem: e.g. one whose profile an iteration has updated)
     hb = hip_backend(prob)
-    start_species(hb, prob)
+    start_species(hb, prob, i_iter)
     ng, IC = prob.n_grid, mcs.capi.IC
     pop = hb.get_population()
     w_in = float(pop.weight.sum())
     ob = oracle_backend(prob, nthreads=8)
-    start_species(ob, prob)
+    start_species(ob, prob, i_iter)
     ob.set_population(pop.slice(0, n_prefix))
     w_out = w_esc_up = 0.0
     n_done = n_up = 0
     reached = 0
+    n_checked = []          # particles compared with the oracle in each of the first pcuts
     I_prev = hb.read_tallies()[1]
     for ip in range(1, len(prob.pcuts) + 1):
         n_use = pop.n
@@ -112,17 +113,21 @@ def _property_run(N, n_prefix=4096, prefix_pcuts=5):
         assert int(d[ng + IC["REASON0"]]) == ns and int(ended.sum()) + ns == n_use
         assert int(d[ng + IC["STEPS_HELIX"]]) == int(np.minimum(f["helix"], 10000).astype(np.int64).sum())
         assert int(d[ng + IC["STEPS_RETRO"]]) == int(f["retro"].astype(np.int64).sum())
-        if ip <= prefix_pcuts:
-            ob.run_pcut(ip, 0)
+        nso = 0
+        if ip <= prefix_pcuts and n_prefix > 0:
+            nso = ob.run_pcut(ip, 0)
             fo = ob.finals()
             for k in fo:
                 assert np.array_equal(bits(f[k][:n_prefix]), bits(fo[k])), f"pcut {ip}: prefix {k}"
-            if ip < prefix_pcuts:
-                assert ns == n_use      # pcuts 1-4 save everybody: i_mult == 1 keeps the prefix aligned
-                ob.new_pcut(1)
+            n_checked.append(n_prefix)
         if ns == 0:
             break
         im = max(N // ns, 1)
+        if ip < prefix_pcuts and n_prefix > 0:
+            # the children of the prefix's saved particles are the first nso * im particles of the next population, with the
+            # same global indices (the split keeps the order): the oracle follows with ITS split of the prefix
+            n_prefix = ob.new_pcut(im) if nso > 0 else 0
+            assert n_prefix == nso * im
         assert hb.new_pcut(im) == ns * im
         pop = hb.get_population()
         src = np.flatnonzero(l_save)
@@ -134,6 +139,7 @@ def _property_run(N, n_prefix=4096, prefix_pcuts=5):
                 want = want / float(im)
             assert np.array_equal(bits(getattr(pop, fld)[o]), bits(want)), f"pcut {ip}: split field {fld} (i_mult {im}, {ns} parents)"
     assert reached >= 30, "the iteration should run into the late pcuts"
+    assert len(n_checked) >= 3 and min(n_checked[:3]) >= 256, n_checked
     w_left = float(pop.weight.sum()) if ns else 0.0
     assert abs(w_out + w_left - w_in) < 1e-9 * w_in
     T, I = hb.read_tallies()
@@ -156,3 +162,35 @@ def test_config1_properties_every_pcut_1e6():
 def test_config2_population_properties_every_pcut_1e7():
     reached, n_done = _property_run(10_000_000)
     print(f"1e7 protons: {reached} pcuts reached, {n_done} exits")
+
+
+def test_config2_1e7_second_iteration_on_the_updated_profile():
+    """BASELINE config[2] at its own size WITH its own loop: iteration 1 of 10^7 protons through driver.run with smoothing on
+    (K4 consumers on the device, iter_finalize, smooth_grid_par, new tables through mcs_set_grid), then iteration 2 -- on the
+    modified profile every zone crossing takes the frame transform -- through the per-pcut property checks of _property_run,
+    the first 4096 particles against the oracle on the same updated tables."""
+    N = 10_000_000
+    itf = mcs.iter_finalize
+    cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, num_iterations=2)
+    prob = mcs.inputs.build_problem(cfg)
+    u_before = prob.ux.copy()
+    hb = hip_backend(prob)
+    res = mcs.driver.run(prob, hb, None, n_itrs=1, smoothing=itf.SmoothingConfig(smooth_shocks=True), species_tallies="light")
+    hb.destroy()
+    (_, fin, ion), = res.iter_finals
+    P, n = prob.params, prob.n_grid
+    assert fin.profile_changed and not np.array_equal(prob.ux, u_before)
+    u = prob.ux[1:n + 1]
+    assert np.all(np.diff(u) <= 1e-12 * P.u0) and u.max() <= P.u0 * (1 + 1e-12) and u.min() >= P.u2 * (1 - 1e-12)
+    assert prob.ux[P.i_shock - 3] < 0.999 * P.u0                      # a precursor has formed
+    assert 4.0 / 3.0 - 0.02 < fin.Gamma_downstream < 5.0 / 3.0 + 0.02
+    assert np.all(np.isfinite(ion.P_psd_par)) and ion.P_psd_par.max() > 0
+    ng, IC = n, mcs.capi.IC
+    I = res.tallies_i64
+    assert int(I[ng + IC["ZONE_FAIL"]]) == 0 and int(I[ng + IC["RETRO_CAP"]]) == 0
+    st = [(s.n_pts_use, s.n_saved, s.i_mult) for s in res.stats]
+    assert all(b[0] == a[1] * a[2] for a, b in zip(st, st[1:])) and len(st) >= 30      # every population is the split of the previous one
+    assert sum(int(I[ng + IC[f"REASON{r}"]]) for r in range(1, 5)) == sum(a[0] - a[1] for a in st)
+    reached, n_done = _property_run(N, prob=prob, i_iter=2)
+    print(f"config[2], 1e7 protons: iteration 1 {res.steps_helix + res.steps_retro} steps, profile updated "
+          f"(u_x at shock-3: {prob.ux[P.i_shock - 3] / P.u0:.4f} u0); iteration 2 on it: {reached} pcuts, {n_done} exits")

@@ -115,7 +115,7 @@ def test_tcut_print_rewrite_on_device_buffers():
     into the device buffer (mcs_write_tallies_part), so iteration 2 accumulates on top of the normalised spectra -- GPU and
     oracle through the same driver, two iterations."""
     N, npc = 4000, 12
-    pg, po = make_problem(N), make_problem(N)
+    pg, po = make_problem(N, num_iterations=2), make_problem(N, num_iterations=2)
     hb, ob = hip_backend(pg), oracle_backend(po, nthreads=8)
     rg = mcs.driver.run(pg, hb, None, n_itrs=2, max_pcuts=npc, tcut_print=True)
     ro = mcs.driver.run(po, ob, None, n_itrs=2, max_pcuts=npc, tcut_print=True)
@@ -715,3 +715,77 @@ def test_fp32_state_variant_statistical_agreement():
     assert int(r32.tallies_i64[ng + IC["ZONE_FAIL"]]) == 0 and int(r32.tallies_i64[ng + IC["RETRO_CAP"]]) == 0
     st64, st32 = r64.steps_helix + r64.steps_retro, r32.steps_helix + r32.steps_retro
     assert abs(st32 / st64 - 1) < 0.03
+
+
+def test_fp32_state_variant_mixed_species():
+    """BASELINE config[4]'s other half: the fp32-state kernel on the species mix (protons + He + electrons, radiative
+    losses, ion -> electron energy transfer) against the fp64 path, same seeds, 10^5 particles per species.  Statistical
+    agreement per species (histories drift apart as roundings differ): ion dN/dp just downstream within 0.15 dex bin by
+    bin and 0.06 in the fitted slope, population sizes of the well-populated pcuts within 4 %, steps within 4 %; the
+    thermal electrons end at the helix cap in their first pcut in both precisions (quirk Q5)."""
+    from test_physics import dndp_slope
+    N = 100_000
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    species = [mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.2)]
+    res, probs = [], []
+    for fp32 in (False, True):
+        prob = make_problem(N, species=species, energy_transfer_frac=0.1, radiation_losses=True, state_fp32=fp32)
+        from mcs_amd import hip_backend as hbm
+        hb = hbm.HipBackend(0); hb.create(prob)
+        res.append(mcs.driver.run(prob, hb, None, n_itrs=1)); probs.append(prob)
+        hb.destroy()
+    r64, r32 = res
+    prob = probs[0]
+    P, L = prob.params, mcs.capi.Layout(prob.params)
+    ng, IC = P.n_grid, mcs.capi.IC
+    assert int(r32.tallies_i64[ng + IC["ZONE_FAIL"]]) == 0 and int(r32.tallies_i64[ng + IC["RETRO_CAP"]]) == 0
+    by_ion = lambda r: {ion: f for (_, ion, f, _) in r.per_species}
+    t64, t32 = by_ion(r64), by_ion(r32)
+    for ion in (1, 2):                       # protons, He: the accelerated power law
+        for zone in (P.i_shock + 3,):
+            s64, s32 = dndp_slope(prob, L, t64[ion], zone), dndp_slope(prob, L, t32[ion], zone)
+            assert abs(s32 - s64) < 0.06, (ion, zone, s32, s64)
+            a = L.view(t64[ion], "psd")[zone - 1].sum(axis=0); b = L.view(t32[ion], "psd")[zone - 1].sum(axis=0)
+            mb = prob.psd_mom_bounds
+            k = np.arange(1, P.num_psd_mom_bins)
+            pc = 10.0 ** (0.5 * (mb[k] + mb[k + 1]))
+            sel = (pc > 30.0) & (pc < 3.0e4)
+            assert np.max(np.abs(np.log10(b[k][sel] / a[k][sel]))) < 0.15, (ion, zone)
+        s32 = {(y.i_ion, y.i_pcut): y for y in r32.stats}       # (the two runs need not reach the same number of pcuts: pair by pcut)
+        big = [(x.n_saved, s32[(x.i_ion, x.i_pcut)].n_saved) for x in r64.stats
+               if x.i_ion == ion and x.n_saved > N // 10 and (x.i_ion, x.i_pcut) in s32]
+        assert len(big) >= 8 and max(abs(x - y) / x for x, y in big) < 0.04, (ion, big)
+    e64 = [s for s in r64.stats if s.i_ion == 3]; e32 = [s for s in r32.stats if s.i_ion == 3]
+    assert e64[0].n_saved == 0 and e32[0].n_saved == 0 and len(e64) == len(e32) == 1      # Q5: the cap ends every thermal electron in pcut 1
+    st64, st32 = r64.steps_helix + r64.steps_retro, r32.steps_helix + r32.steps_retro
+    assert abs(st32 / st64 - 1) < 0.04
+
+
+def test_config0_stock_input_shape_vs_oracle():
+    """BASELINE config[0]: the stock mc_in.toml at 10^4 particles, one iteration -- two species (protons and electrons),
+    no-scatter = true and no-DSA = true (the committed file is a scatter-free plumbing run, /root/reference/mc_in.toml:136,139),
+    radiative losses, energy-transfer-frac 0.1, compressed turbulence in the field, the custom-eps_B flag, the stock time and
+    momentum cuts -- on the GPU and on the oracle through the same driver; integers, populations and binned tallies must
+    agree as in every other whole-iteration test.  Two things of the stock file cannot be taken literally: DENZ_ION = [1, 0]
+    gives the electrons zero weight and electron_weight_fac = 1/0 (quirk G4: n_e = n_p is used), and the custom-eps_B
+    PROFILE comes from an initialiser outside the path (the flag is set on the compressed-turbulence tables)."""
+    N = 10_000
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.0)],
+              no_scatter=True, no_DSA=True, radiation_losses=True, energy_transfer_frac=0.1, b_field_turbulence=1.0,
+              b_field_amplify=1.0, electron_energy_mfp_threshold=1e4)
+    pg, po = make_problem(N, **kw), make_problem(N, **kw)
+    pg.params.use_custom_epsB = 1; po.params.use_custom_epsB = 1
+    hb, ob = hip_backend(pg), oracle_backend(po, nthreads=16)
+    rg = mcs.driver.run(pg, hb, None, n_itrs=1, finalize=True)
+    ro = mcs.driver.run(po, ob, None, n_itrs=1, finalize=True)
+    assert len({s.i_ion for s in rg.stats}) == 2
+    assert [(s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in rg.stats] == [(s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in ro.stats]
+    assert np.array_equal(rg.tallies_i64, ro.tallies_i64)
+    assert_tallies_close(hb.layout, rg.tallies_f64, ro.tallies_f64, TALLY_RTOL)
+    ng, IC = pg.n_grid, mcs.capi.IC
+    assert int(rg.tallies_i64[ng + IC["RNG_DRAWS"]]) >= 0 and rg.steps_helix > N      # scatter-free: the particles advect through the grid
+    (_, fg, _), = rg.iter_finals
+    (_, fo, _), = ro.iter_finals
+    assert abs(fg.Gamma_downstream / fo.Gamma_downstream - 1) < 1e-9
+    hb.destroy(); ob.destroy()
