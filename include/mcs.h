@@ -314,6 +314,15 @@ int mcs_dndp_cr(mcs_ctx* ctx, const mcs_consumer_in* in, double* dNdp, int64_t* 
  * Outputs: host [n_grid] each. */
 int mcs_thermo_calcs(mcs_ctx* ctx, const mcs_consumer_in* in, double* P_par, double* P_perp, double* energy_density);
 
+/* ---- photon post-processing: the synchrotron fold of src/synch_emission.jl:27-171 over the plasma-frame
+ * dN/dp of an electron species (frame 2 of mcs_dndp_cr), for every grid zone with the zone's field of the grid tables.
+ * dNdp_pf: host [n_grid][nmom+2]; mom_edge_cgs: host [nmom+2]; mc of the species; photon energies
+ * E_j = emin_mev * 10^(j / bins_per_dec), j = 0 .. n_photon-1 (photon_calcs.jl:11-19,51: 1e-13 MeV, 10 per decade, 180 bins).
+ * Outputs (host): energy_erg[n_photon] (may be null), emis[n_grid][n_photon] = dP/d(ln E) in erg/s per zone, floor 1e-99.
+ * The photon stack is dead code in the reference and is followed as specification; F(x) is restated (include/mcs_synch.h). */
+int mcs_photon_synch(mcs_ctx* ctx, const double* dNdp_pf, const double* mom_edge_cgs, double mc, int n_photon, double emin_mev,
+                     double bins_per_dec, double* energy_erg, double* emis);
+
 /* ---- test / measurement hooks ------------------------------------------- */
 /* evaluate device math/RNG primitives (bit-parity tests): fn ids in mcs_fn */
 enum mcs_fn { MCS_FN_SIN = 0, MCS_FN_COS, MCS_FN_ASIN, MCS_FN_ACOS, MCS_FN_ATAN2, MCS_FN_LOG10,

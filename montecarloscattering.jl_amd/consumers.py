@@ -159,3 +159,43 @@ def ion_finalize(prob, backend, i_ion: int, therm_from_hist: bool = True) -> Ion
     dndp, diag = backend.dndp_cr(tabs)
     ppar, pperp, edens = backend.thermo_calcs(tabs)
     return IonFinal(dndp, tabs.zone_pop, ppar, pperp, edens, diag)
+
+
+# ---- photon post-processing -------------------------------------------------------------------------
+# photon_calcs.jl:11-19: the common energy grid of the emission spectra
+PHOTON_E_MIN_MEV = 1.0e-13
+PHOTON_BINS_PER_DEC = 10
+PHOTON_SYNCH_E_MAX_MEV = 1.0e5
+MEV_ERG = 1.602176634e-6
+KPC_CM = 3.0856775814913674e21
+
+
+@dataclasses.dataclass
+class PhotonSynch:
+    """What `photon_synch` computes per grid zone (src/photon_synch.jl:28-133) -- it writes it to photon_synch_grid.dat."""
+    energy_MeV: np.ndarray         # [n_photon]
+    emis_erg_s: np.ndarray         # [n_grid][n_photon]  dP/d(ln E) emitted by the zone
+    energy_flux_MeV: np.ndarray    # [n_grid][n_photon]  MeV / (cm^2 s) per d(ln E) at Earth, floor 1e-99
+    photon_flux: np.ndarray        # [n_grid][n_photon]  photons / (cm^2 s) per d(ln E) at Earth, floor 1e-99
+
+
+def photon_synch(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: float = 1.0e6, redshift: float = 0.0) -> PhotonSynch:
+    """The synchrotron branch of `photon_calcs` (src/photon_calcs.jl:27-113) for an electron species: per zone, the fold of
+    src/synch_emission.jl over the plasma-frame dN/dp (frame 2 of get_dNdp_cr; the thermal part is empty, quirk C4), on the
+    device (K5), then photon_synch's conversion to fluxes at Earth (src/photon_synch.jl:74-108) with the luminosity distance
+    of photon_calcs.jl:40.  The photon stack is dead code in the reference: followed as
+    specification.  Inverse Compton needs d2N/dp dcos in the explosion frame, which get_dNdp_2D never produces (C4): not built;
+    pion decay concerns nuclei."""
+    P = prob.params
+    sp = prob.cfg.species[i_ion - 1]
+    if sp.aa >= 1:
+        raise ValueError("photon_synch: synchrotron emission is computed for the electron species (aa < 1)")
+    tabs = consumer_tables(prob, i_ion)
+    n_photon = int(math.log10(PHOTON_SYNCH_E_MAX_MEV / PHOTON_E_MIN_MEV) * PHOTON_BINS_PER_DEC)      # photon_calcs.jl:51
+    E_erg, emis = backend.photon_synch(ion_fin.dNdp_cr[1], tabs.mom_edge_cgs, tabs.mc, n_photon, PHOTON_E_MIN_MEV, PHOTON_BINS_PER_DEC)
+    dist_lum = jet_dist_kpc * (1 + redshift) * KPC_CM
+    E_MeV = E_erg / MEV_ERG
+    flux_erg = np.maximum(emis / (4 * math.pi * dist_lum ** 2), 1.0e-99)
+    eflux_MeV = np.where(flux_erg > 1.0e-99, flux_erg / MEV_ERG, 1.0e-99)
+    pflux = np.where(eflux_MeV <= 1.0e-99, 1.0e-99, eflux_MeV / E_MeV[None, :])
+    return PhotonSynch(E_MeV, emis, eflux_MeV, pflux)

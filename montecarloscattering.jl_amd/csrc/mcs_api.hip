@@ -38,11 +38,14 @@ hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStrea
 hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b, double* out, hipStream_t st);
 hipError_t mcs_launch_dndp_cr(const mcs_params* P, const double* psd, const double* gam_sf, const double* ux, const double* tabs,
                               double rest_energy, double n0, double gam0, double* out_dndp, unsigned long long* diag, hipStream_t st);
+hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
+                                   double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st);
 hipError_t mcs_launch_thermo(const mcs_params* P, const double* psd, const double* therm_pf, const unsigned long long* num_crossings,
                              const double* gam_sf, const double* ux, const double* tabs, double rest_energy, double mc, double n0,
                              int therm_from_hist, double* scratch, double* out3, hipStream_t st);
 }
 
+#define MCS_MEV_ERG_ 1.602176634e-6
 namespace {
 thread_local std::string g_err;
 
@@ -104,8 +107,10 @@ struct mcs_ctx {
   unsigned long long* d_counters = nullptr;   // [0] work counter, [1] n_saved, [2] scan total
   // staging for init_pop
   double* d_stage = nullptr; long long stage_cap = 0;
-  // launch constants: host copy (stable address for the async upload) and device copy
-  KArgs h_args; KArgs* d_args = nullptr;
+  // launch constants: host copy in PINNED memory (the upload is then a true async copy: no staging through the runtime's
+  // bounce buffer, ~10 us per pcut) and device copy; read-back words of a pcut, pinned for the same reason
+  KArgs* h_args_pin = nullptr; KArgs* d_args = nullptr;
+  unsigned long long* h_back = nullptr;       // [0..1] n_saved | count of l_save flags, [2] exported particles of a sliced run
   // species
   int i_iter = 1, i_ion = 1;
   double aa = 1, zzq = MCS_QCGS, m = MCS_MP, mc = MCS_MP * MCS_C, pmax_cutoff = 0, density = 1, ewf = 1;
@@ -283,6 +288,8 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   CRCHK(hipMalloc((void**)&c->d_tab, (size_t)8 * ne * sizeof(double)));
   CRCHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)));
   CRCHK(hipMalloc((void**)&c->d_args, sizeof(KArgs)));
+  CRCHK(hipHostMalloc((void**)&c->h_args_pin, sizeof(KArgs)));
+  CRCHK(hipHostMalloc((void**)&c->h_back, 4 * sizeof(unsigned long long)));
   { const char* e = std::getenv("MCS_TALLY_REPLICAS_OFF"); c->tally_replicas = !(e && e[0] == '1'); }
   if (c->tally_replicas) {
     c->rep_n = c->L.total;     // the whole tally buffer: the three big histograms are 99 % of it
@@ -316,6 +323,8 @@ int mcs_destroy(mcs_ctx* c) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
+  if (c->h_args_pin) (void)hipHostFree(c->h_args_pin);
+  if (c->h_back) (void)hipHostFree(c->h_back);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -628,7 +637,7 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
     for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void**)&c->d_strag[b], (size_t)c->strag_cap * MCS_STRAG_WORDS * sizeof(double)));
   }
 
-  KArgs& a = c->h_args;
+  KArgs& a = *c->h_args_pin;     // (every launch below is followed by a stream synchronisation before this is written again)
   std::memset(&a, 0, sizeof(a));
   a.P = c->P; a.L = c->L; a.tb = c->tb; a.in = c->cur.d; a.sv = c->sav.d; a.l_save = c->d_lsave;
   a.T = c->d_T; a.I = c->d_I;
@@ -681,7 +690,7 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
   for (int round = 0;; ++round) {
-    HIPCHK(hipMemcpyAsync(c->d_args, &c->h_args, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
       if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, blocks, 256, c->stream));
@@ -694,9 +703,9 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
     // sliced run: how many particles did the launch export?  They are the next launch's queue, spread over the chip's waves:
     // a pass costs a wave the same with 1 live lane as with 64, but the rare work of every live lane stalls all the others,
     // so the fewer particles share a wave the faster each history advances -- and the launch waits for its longest one.
-    unsigned long long n_x = 0;
-    HIPCHK(hipMemcpyAsync(&n_x, c->d_counters + 3, sizeof(n_x), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_back + 2, c->d_counters + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const unsigned long long n_x = c->h_back[2];
     float ms_r = 0.f;
     HIPCHK(hipEventElapsedTime(&ms_r, c->ev0, c->ev1));
     ms_total += ms_r;
@@ -724,9 +733,9 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
   // independent count of the l_save flags next to the kernel's own n_saved counter, read back together
   HIPCHK(mcs_launch_compact(c->d_lsave, n, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src, c->stream));
-  unsigned long long ns[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(ns, c->d_counters + 1, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_back, c->d_counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  const unsigned long long ns[2] = {c->h_back[0], c->h_back[1]};
   if (budget == 0) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -926,6 +935,27 @@ int mcs_thermo_calcs(mcs_ctx* c, const mcs_consumer_in* in, double* P_par, doubl
   memcpy(P_par, o.data(), sizeof(double) * ng);
   memcpy(P_perp, o.data() + ng, sizeof(double) * ng);
   memcpy(energy_density, o.data() + 2 * ng, sizeof(double) * ng);
+  return 0;
+}
+
+int mcs_photon_synch(mcs_ctx* c, const double* dNdp_pf, const double* mom_edge_cgs, double mc, int n_photon, double emin_mev,
+                     double bins_per_dec, double* energy_erg, double* emis) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (!c || !dNdp_pf || !mom_edge_cgs || !emis) return fail("mcs_photon_synch: null argument");
+  if (!c->have_grid) return fail("mcs_photon_synch: grid not set");
+  if (n_photon < 1 || n_photon > 4096 || !(emin_mev > 0) || !(bins_per_dec > 0) || !(mc > 0)) return fail("mcs_photon_synch: bad arguments");
+  const int NM = c->P.num_psd_mom_bins + 2, ng = c->P.n_grid;
+  if (NM > 208) return fail("mcs_photon_synch: too many momentum bins");
+  const size_t n_in = (size_t)ng * NM + NM, n_out = (size_t)ng * n_photon;
+  if (ensure_stage(c, (long long)(n_in + n_out) + 4)) return 1;
+  double* d_in = c->d_stage; double* d_out = c->d_stage + n_in;
+  HIPCHK(hipMemcpyAsync(d_in, dNdp_pf, sizeof(double) * (size_t)ng * NM, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_in + (size_t)ng * NM, mom_edge_cgs, sizeof(double) * NM, hipMemcpyHostToDevice, c->stream));
+  const double log_emin = std::log10(emin_mev * MCS_MEV_ERG_);
+  HIPCHK(mcs_launch_photon_synch(d_in, d_in + (size_t)ng * NM, c->tb.btot, ng, NM, n_photon, log_emin, bins_per_dec, mc, d_out, c->stream));
+  HIPCHK(hipMemcpyAsync(emis, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (energy_erg) for (int j = 0; j < n_photon; ++j) energy_erg[j] = std::pow(10.0, log_emin + j * (1.0 / bins_per_dec));
   return 0;
 }
 

@@ -14,6 +14,7 @@
 // The reference's consumer quirks C1-C6 are handled as DESIGN.md section 3b says.
 #include "mcs_device.h"
 #include "../../include/mcs_math.h"
+#include "../../include/mcs_synch.h"
 
 #pragma clang fp contract(off)
 
@@ -185,8 +186,14 @@ __global__ void __launch_bounds__(256) mcs_k_dndp_cr(ConsArgs a) {
       c_corner(gam, beta, a.rest_energy, s_pe[i + 1], s_ce[j + 1], pts[3], cts[3]);
       double p_lo, p_hi, clo, chi;
       if (!c_identify(pts, cts, p_lo, p_hi, clo, chi)) { atomicAdd(&a.diag[0], 1ull); continue; }
+      // first edge above p_lo, minus one (the reference scans; the edges increase, so a bisection finds the same index in 8
+      // dependent LDS reads instead of up to 174: the scan was most of this kernel's time)
       int l_lo = -1;
-      for (int l = 0; l < NM; ++l) if (s_lb[l] > p_lo) { l_lo = l - 1; break; }
+      {
+        int lo = 0, hi = NM;                       // smallest l in [0, NM) with s_lb[l] > p_lo, NM if there is none
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_lb[mid] > p_lo) hi = mid; else lo = mid + 1; }
+        if (lo < NM) l_lo = lo - 1;
+      }
       if (l_lo < 0) { l_lo = nm; atomicAdd(&a.diag[1], 1ull); }
       int l_hi = -1;
       for (int l = l_lo; l < NM; ++l) if (s_lb[l] >= p_hi) { l_hi = l; break; }
@@ -358,5 +365,30 @@ extern "C" hipError_t mcs_launch_thermo(const mcs_params* P, const double* psd, 
   a.rest_energy = rest_energy; a.mc = mc; a.n0 = n0; a.therm_from_hist = therm_from_hist;
   a.scratch = scratch; a.out_par = out3; a.out_perp = out3 + ng; a.out_edens = out3 + 2 * ng;
   hipLaunchKernelGGL(mcs_k_thermo, dim3(P->n_grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+
+// ---- K5: the synchrotron fold of the photon post-processing (include/mcs_synch.h) ------------------------
+// One workgroup per grid zone, one thread per photon energy; every thread walks the electron momentum bins in the reference's
+// order (synch_emission.jl:124-169), so a spectrum is the same sum in the same order on the CPU twin.  O(n_grid x n_photon x nmom)
+// evaluations of F(x): 3e6 for the stock binning -- microseconds of the chip; it runs where the dN/dp it reads was made.
+__global__ void __launch_bounds__(256) mcs_k_photon_synch(const double* __restrict__ dndp_pf /*[n_grid][NM]*/, const double* __restrict__ p_edge /*[NM]*/,
+                                                         const double* __restrict__ btot /*[n_grid+2]*/, int NM, int n_photon, double log_emin_erg,
+                                                         double bins_per_dec, double mc, double* __restrict__ out /*[n_grid][n_photon]*/) {
+  __shared__ double s_d[KC_MAXB], s_p[KC_MAXB];
+  const int zone = blockIdx.x + 1;
+  for (int i = threadIdx.x; i < NM; i += blockDim.x) { s_d[i] = dndp_pf[(long long)(zone - 1) * NM + i]; s_p[i] = p_edge[i]; }
+  __syncthreads();
+  const double B = btot[zone];
+  for (int j = threadIdx.x; j < n_photon; j += blockDim.x) {
+    const double E = mcs_synch_energy(log_emin_erg, bins_per_dec, j);
+    out[(long long)(zone - 1) * n_photon + j] = mcs_synch_fold_one(1.0e-99, s_d, s_p, NM - 2, B, mc, E);     // fill(1e-99), :64
+  }
+}
+
+extern "C" hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
+                                              double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(mcs_k_photon_synch, dim3((unsigned)n_grid), dim3(256), 0, st, dndp_pf, p_edge, btot, NM, n_photon, log_emin_erg, bins_per_dec, mc, out);
   return hipGetLastError();
 }

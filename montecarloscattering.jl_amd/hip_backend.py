@@ -282,6 +282,14 @@ class HipBackend:
         self._chk(self.lib.mcs_thermo_calcs(self.h, ct.byref(s), _dp(a), _dp(b), _dp(c)))
         return a, b, c
 
+    def photon_synch(self, dndp_pf, mom_edge_cgs, mc, n_photon, emin_mev, bins_per_dec):
+        """K5: synchrotron emission dP/d(ln E) [erg/s] per zone from the plasma-frame electron dN/dp -> (E_erg[n_photon], emis[n_grid][n_photon])."""
+        d = np.ascontiguousarray(dndp_pf, dtype=np.float64); pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        assert d.shape == (self.P.n_grid, self.P.num_psd_mom_bins + 2) and pe.shape == (self.P.num_psd_mom_bins + 2,)
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.mcs_photon_synch(self.h, _dp(d), _dp(pe), float(mc), int(n_photon), float(emin_mev), float(bins_per_dec), _dp(E), _dp(out)))
+        return E, out
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.mcs_last_kernel_ms(self.h))
 

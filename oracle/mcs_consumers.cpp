@@ -30,6 +30,7 @@
 //    src/transformers.jl:213-214, i.e. the triangle height is off by (p_hi-p_lo)^2; the last
 //    bin absorbs the remainder so the cell weight is conserved.)
 #include "../include/mcs.h"
+#include "../include/mcs_synch.h"
 
 #include <cmath>
 #include <cstdint>
@@ -316,5 +317,21 @@ int orc_thermo_calcs(const mcs_params* Pp, const double* T, const int64_t* I, co
   }
   return 0;
 }
+
+// The synchrotron fold (src/synch_emission.jl:27-171 through src/photon_synch.jl:28-72), CPU twin of
+// mcs_photon_synch: the same header (include/mcs_synch.h), glibc math.
+int orc_photon_synch(const mcs_params* Pp, const double* dNdp_pf, const double* mom_edge_cgs, const double* btot /*[n_grid+2]*/, double mc,
+                     int n_photon, double emin_mev, double bins_per_dec, double* energy_erg, double* emis) {
+  const int NM = Pp->num_psd_mom_bins + 2, ng = Pp->n_grid;
+  const double log_emin = std::log10(emin_mev * MCS_MEV_ERG);
+  for (int zone = 1; zone <= ng; ++zone)
+    for (int j = 0; j < n_photon; ++j) {
+      const double E = mcs_synch_energy(log_emin, bins_per_dec, j);
+      if (zone == 1 && energy_erg) energy_erg[j] = E;
+      emis[(size_t)(zone - 1) * n_photon + j] = mcs_synch_fold_one(1.0e-99, dNdp_pf + (size_t)(zone - 1) * NM, mom_edge_cgs, NM - 2, btot[zone], mc, E);
+    }
+  return 0;
+}
+double orc_synch_F(double x) { return mcs_synch_F(x); }
 
 }  // extern "C"

@@ -72,6 +72,8 @@ def load(math: str = "det", capi=None):
         cin_p = ct.POINTER(capi.McsConsumerIn)
         sig["orc_dndp_cr"] = (i32, [par_p, dp, cin_p, dp, dp, dp, i64p])
         sig["orc_thermo_calcs"] = (i32, [par_p, dp, i64p, cin_p, dp, dp, dp, dp, dp])
+        sig["orc_photon_synch"] = (i32, [par_p, dp, dp, dp, dbl, i32, dbl, dbl, dp, dp])
+        sig["orc_synch_F"] = (dbl, [dbl])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -258,6 +260,14 @@ class OracleBackend:
         f, i = self.read_tallies()
         self.layout.view(f, name)[...] = np.asarray(arr).reshape(self.layout.shapes[name])
         self.write_tallies(f, i)
+
+    def photon_synch(self, dndp_pf, mom_edge_cgs, mc, n_photon, emin_mev, bins_per_dec):
+        d = np.ascontiguousarray(dndp_pf, dtype=np.float64); pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        bt = np.ascontiguousarray(self.prob.btot, dtype=np.float64)
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.orc_photon_synch(ct.byref(self.P), _dp(d), _dp(pe), _dp(bt), float(mc), int(n_photon), float(emin_mev),
+                                            float(bins_per_dec), _dp(E), _dp(out)))
+        return E, out
 
     # -- consumers of the tallies (oracle/mcs_consumers.cpp)
     def dndp_cr(self, tabs, tallies=None):
