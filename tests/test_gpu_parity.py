@@ -3,6 +3,7 @@ real MI355X.  Bar: bit-exact for everything per particle (end state, saved popul
 split population, RNG consumption, step counts, integer tallies); fp64 tallies agree up to
 the order of the atomic adds: |gpu - oracle| <= 1e-11 * max|oracle| per tally array."""
 import ctypes as ct
+import sys
 
 import numpy as np
 import pytest
@@ -713,8 +714,22 @@ def test_fp32_state_variant_statistical_agreement():
     assert len(big) >= 12 and max(abs(x - y) / x for x, y in big) < 0.03
     ng, IC = P.n_grid, mcs.capi.IC
     assert int(r32.tallies_i64[ng + IC["ZONE_FAIL"]]) == 0 and int(r32.tallies_i64[ng + IC["RETRO_CAP"]]) == 0
-    st64, st32 = r64.steps_helix + r64.steps_retro, r32.steps_helix + r32.steps_retro
-    assert abs(st32 / st64 - 1) < 0.03
+    # total steps: one realisation scatters by ~3 % at this N (the late pcuts are replicas of a handful of survivors: measured
+    # 2.78 .. 2.85e9 for fp64 and 2.72 .. 2.88e9 for fp32 over the seeds of three iterations, tools/gpu_steps_noise.py), so the MEANS
+    # of three realisations are compared, and every fp32 realisation with the fp64 mean
+    def steps(fp32, it):
+        cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, state_fp32=fp32, num_iterations=3)
+        pr = mcs.inputs.build_problem(cfg)
+        from mcs_amd import hip_backend as hbm2
+        hb2 = hbm2.HipBackend(0); hb2.create(pr)
+        rr = mcs.driver.run(pr, hb2, None, n_itrs=1, first_iter=it)
+        hb2.destroy()
+        return rr.steps_helix + rr.steps_retro
+    s64 = [r64.steps_helix + r64.steps_retro, steps(False, 2), steps(False, 3)]
+    s32 = [r32.steps_helix + r32.steps_retro, steps(True, 2), steps(True, 3)]
+    m64, m32 = float(np.mean(s64)), float(np.mean(s32))
+    assert abs(m32 / m64 - 1) < 0.03, (s64, s32)
+    assert max(abs(x / m64 - 1) for x in s32) < 0.07, (s64, s32)
 
 
 def test_fp32_state_variant_mixed_species():
@@ -789,3 +804,70 @@ def test_config0_stock_input_shape_vs_oracle():
     (_, fo, _), = ro.iter_finals
     assert abs(fg.Gamma_downstream / fo.Gamma_downstream - 1) < 1e-9
     hb.destroy(); ob.destroy()
+
+
+def _run_fp32(monkeypatch, loop, N, n_pcuts, **kw):
+    """finals + saved arrays of every pcut and the tallies of the fp32-state variant, plain loop or organised kernel"""
+    monkeypatch.setenv("MCS_F32_LOOP", "1" if loop else "0")
+    prob = make_problem(N, state_fp32=True, **kw)
+    hb = hip_backend(prob)
+    out = []
+    for i_ion in range(1, len(prob.cfg.species) + 1):
+        start_species(hb, prob, 1, i_ion) if i_ion == 1 else None
+        if i_ion > 1:
+            sp = prob.cfg.species[i_ion - 1]
+            inj = mcs.inputs.init_pop_host(prob, i_ion)
+            pmax = mcs.inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
+            hb.begin_species(1, i_ion, sp.aa, abs(sp.zz), pmax, sp.density, 1.0 / prob.cfg.species[-1].density)
+            hb.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+            hb.init_pop(inj, 0, inj.n_pts_use, inj.n_pts_use)
+        for ip in range(1, n_pcuts + 1):
+            ns = hb.run_pcut(ip, 0)
+            f = hb.finals(); sv, ls = hb.get_saved()
+            out.append((i_ion, ip, ns, f, sv, ls))
+            if ns == 0:
+                break
+            hb.new_pcut(max(N // ns, 1))
+    T, I = hb.read_tallies()
+    hb.destroy()
+    return out, T, I, prob
+
+
+@pytest.mark.parametrize("case", ["protons", "mixed", "oblique_modified"])
+def test_fp32_kernels_agree(monkeypatch, case):
+    """The fp32-state variant exists twice: as a plain per-lane loop (mcs_k_transport_f32_loop: the reference's loop body as
+    written, in fp32 -- what defines the variant) and organised like the fp64 kernel (mcs_k_transport_f32: flag-driven common
+    pass, cached slowly varying quantities, position thresholds, deferred tallies).  Both use the same fp32 helper functions in
+    the same order per particle, so they must agree BIT FOR BIT on every particle's end state and saved state, on the integer
+    tallies, and on the fp64 tallies up to the order of the adds."""
+    kw, N, npc = {}, 6000, 9
+    tweak = None
+    if case == "mixed":
+        me_mp = mcs.constants.ME / mcs.constants.MP
+        kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.0)], energy_transfer_frac=0.1,
+                  radiation_losses=True, XSPEC=[-0.5, 0.05, 2.0], INJFR=[0.7, 1.0], b_field_turbulence=1.0, shock_speed=3.0)
+        N, npc = 1500, 7
+    res = []
+    for loop in (True, False):
+        if case == "oblique_modified":
+            # (tables are edited after build_problem: done inside through a patched make_problem)
+            import conftest
+            orig = conftest.make_problem
+            def mp(Nn, **k2):
+                pr = orig(Nn, **k2)
+                modified_profile(pr)
+                pr.theta = np.where(pr.x_grid_cm < 0, 0.35, 0.8); pr.uz = 0.05 * pr.ux; pr.utot = np.hypot(pr.ux, pr.uz)
+                pr.gam_sf = 1 / np.sqrt(1 - (pr.utot / mcs.constants.C) ** 2)
+                return pr
+            monkeypatch.setattr(sys.modules[__name__], "make_problem", mp)
+        res.append(_run_fp32(monkeypatch, loop, N, npc, **kw))
+    (oa, Ta, Ia, prob), (ob_, Tb, Ib, _) = res
+    assert len(oa) == len(ob_) and len(oa) >= 5
+    for (ia, pa, nsa, fa, sa, la), (ib, pb, nsb, fb, sb, lb) in zip(oa, ob_):
+        assert (ia, pa, nsa) == (ib, pb, nsb), (ia, pa, nsa, nsb)
+        for k in fa:
+            assert np.array_equal(bits(fa[k]), bits(fb[k])), f"ion {ia} pcut {pa}: final {k} differs for {(fa[k] != fb[k]).sum()} particles"
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, f"ion {ia} pcut {pa}: saved arrays")
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(mcs.capi.Layout(prob.params), Tb, Ta, TALLY_RTOL)

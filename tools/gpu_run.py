@@ -8,7 +8,8 @@ from mcs_amd import hip_backend
 N = int(sys.argv[1]); NPC = int(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 MOD = len(sys.argv) > 4 and sys.argv[4] == "mod"      # precursor profile: u_x differs in every upstream zone
-cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N)
+FP32 = "fp32" in sys.argv[4:]                         # the fp32-state variant (MCS_F32_LOOP=1: its plain-loop form)
+cfg = m.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, state_fp32=FP32)
 prob = m.inputs.build_problem(cfg)
 if MOD:
     C = m.constants.C
