@@ -287,12 +287,12 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     # every rank splits its own saved particles; the index column alone goes round
                     g_loc = backend.saved_gidx()                                  # ascending, counts[rank] entries
                     cap = max(max(counts), 1)
-                    pad = torch.zeros(cap, dtype=torch.int64, device=g_loc.device)
+                    # (padded with the largest int64: every row of the gathered table stays sorted, so ONE batched searchsorted
+                    # counts, for each of my saved particles, the saved particles of every rank below it)
+                    pad = torch.full((cap,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=g_loc.device)
                     pad[:g_loc.numel()] = g_loc
                     g_all = comm.all_gather_rows(pad)                             # [W, cap]
-                    pos = torch.zeros_like(g_loc)
-                    for r in range(comm.world):                                   # saved particles of rank r below each of mine
-                        pos += torch.searchsorted(g_all[r, :counts[r]].contiguous(), g_loc)
+                    pos = torch.searchsorted(g_all, g_loc.unsqueeze(0).expand(g_all.shape[0], -1).contiguous()).sum(dim=0)
                     gidx = (pos[:, None] * i_mult + torch.arange(i_mult, dtype=torch.int64, device=g_loc.device)[None, :]).reshape(-1).contiguous()
                     backend.new_pcut(i_mult)
                     n_local = counts[comm.rank] * i_mult
