@@ -348,9 +348,12 @@ int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
  * ends; the library relaunches them spread over the chip's waves -- a particle that shares its wave with few others
  * advances faster, its neighbours' rare work no longer stalls it -- until none is left.  A history is the same bit for
  * bit however often it is suspended (state and RNG stream position travel with the particle).
- * mcs_last_launches: launches the last mcs_run_pcut* took. */
+ * mcs_last_launches: launches the last mcs_run_pcut* took.
+ * mcs_last_kernel: which transport kernel they ran -- 0 the general kernel, 1 its specialisation for the common configuration,
+ * 2 the one for electrons with radiative losses, 3 the fp32-state kernel, 4 its plain-loop form. */
 int mcs_set_tail_slicing(mcs_ctx* ctx, int budget_trips);
 int mcs_last_launches(mcs_ctx* ctx);
+int mcs_last_kernel(mcs_ctx* ctx);
 /* compute units of the context's device (the default grid of mcs_run_pcut* is 2 workgroups per CU; a caller that keeps two
  * contexts busy on one device gives each of them one per CU: mcs_set_launch(ctx, mcs_num_cus(ctx), 256)) */
 int mcs_num_cus(mcs_ctx* ctx);

@@ -238,6 +238,7 @@ def load_library() -> ct.CDLL:
         "mcs_set_launch": (i32, [vp, i32, i32]),
         "mcs_set_tail_slicing": (i32, [vp, i32]),
         "mcs_last_launches": (i32, [vp]),
+        "mcs_last_kernel": (i32, [vp]),
         "mcs_get_layout": (i32, [ct.POINTER(McsParams), c_int64_p]),
         "mcs_dndp_cr": (i32, [vp, ct.POINTER(McsConsumerIn), c_double_p, c_int64_p]),
         "mcs_thermo_calcs": (i32, [vp, ct.POINTER(McsConsumerIn), c_double_p, c_double_p, c_double_p]),
@@ -259,5 +260,5 @@ EXPORTED_SYMBOLS = [
     "mcs_write_tallies", "mcs_eval_fn", "mcs_final_download", "mcs_last_kernel_ms", "mcs_set_launch",
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
     "mcs_run_pcut_strided", "mcs_run_pcut_indexed", "mcs_saved_gidx", "mcs_init_pop_binned_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
-    "mcs_set_tail_slicing", "mcs_last_launches", "mcs_write_tallies_part", "mcs_photon_synch",
+    "mcs_set_tail_slicing", "mcs_last_launches", "mcs_last_kernel", "mcs_write_tallies_part", "mcs_photon_synch",
 ]

@@ -17,7 +17,7 @@
 extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
-hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st);
+hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int loop, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
@@ -119,6 +119,7 @@ struct mcs_ctx {
   bool have_grid = false, have_cuts = false;
   bool all_parallel = false;   // theta == 0 in every zone (mcs_set_grid)
   bool tail_merge = true;      // MCS_TAIL_MERGE=0: no consolidation of sparse waves (A/B measurements)
+  int kernel_last = -1;        // mcs_last_kernel
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
   // consumers (K4): table staging, outputs, thermo scratch slab
   double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
@@ -601,6 +602,7 @@ int mcs_set_tail_slicing(mcs_ctx* c, int budget_trips) {
   return 0;
 }
 int mcs_last_launches(mcs_ctx* c) { return c->tail_rounds_last; }
+int mcs_last_kernel(mcs_ctx* c) { return c->kernel_last; }
 int mcs_set_retro_cap(mcs_ctx* c, int64_t cap) {
   if (cap < 0 || cap > 2000000000LL) return fail("mcs_set_retro_cap: cap out of range");
   c->retro_cap = cap > 0 ? (int)cap : MCS_RETRO_CAP;
@@ -693,14 +695,17 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                      !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
                      c->tb.n_xspec == 0 && !(a.inj_frac < 1);
+  // the specialised kernel for electrons with radiative losses (transport_body<false, LOSSY>): the loss in line in the common pass
+  const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
+  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : 3) : (plain ? 1 : (lossy ? 2 : 0));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
       if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : 0, blocks, 256, c->stream));
-      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : 0, blocks, threads, c->stream));
+      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : (lossy ? 2 : 0), blocks, threads, c->stream));
       c->rep_dirty = true;
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));

@@ -206,6 +206,9 @@ __shared__ unsigned int S_evcur[4];         // per-wave stack height
 #define F_CM      0x200   // only cos_max is stale (fine/coarse switch in the last pass): refresh_scatter alone
 #define F_NOPARK  0x400   // just loaded, or released from waiting: run the full Code Blocks now
 #define F_WAIT    0x800   // needs the full Code Blocks and waits for company (see "Waiting" in transport_body): sits out the common passes
+#define F_INJCHK  0x2000  // loaded downstream-flagged, not injected, at x < 0 (a state only a caller's own population has): the `inj` update
+                          // that follows EVERY move in the reference (particle_loop.jl:433-435) is due after the first move -- slow_post, event or not
+#define F_LOST    0x1000  // LOSSY kernel: the in-line radiative loss of the pass left no momentum (particle_loop.jl:578-592 -> finish code 4)
 struct Pt {
   double weight, ptot_pf, pb_pf, p_perp, gam_pf, x, x_old, phi, prp, acctime, xn_per;
   double dphi;                   // 2pi / xn_per (particle_loop.jl:529)
@@ -412,6 +415,27 @@ __device__ __forceinline__ void refresh_scatter(CK* a, Pt& p, double aa, double 
   const double vp_tg = TWOPI_ * grt;
   const double lam = eta * grt;
   p.cm_val = mcsm::cos(__builtin_sqrt(6 * vp_tg / (p.xn_per * lam)));
+  p.rp_val = rcp_refined(p.ptot_pf);
+}
+
+// The same statements for the in-line loss of the LOSSY kernel: the constants handed in (they sit in registers; `a->P.x` in the
+// loop is an s_load + wait), the division, the square root and the cosine in the forms of the common pass -- fdiv (the quotient
+// of the compiler's own sequence without the range rescale), the square root without its class test, sincos with the
+// coefficients from the table in VGPRs: bit-identical results (see rcp_refined, mcsm::sqrt_nn_, mcsm::sincos_t)
+__device__ __forceinline__ void refresh_scatter_k(Pt& p, const mcsm::HotCoef& kc, double aa, double mc, double eta, double pe_crit, double game_crit) {
+  double grt;
+  if (aa < 1 && p.ptot_pf < pe_crit) {
+    grt = pe_crit * CC_ * p.gyro_denom;
+    p.gyro_period = TWOPI_ * game_crit * mc * p.gyro_denom;
+  } else {
+    grt = p.ptot_pf * CC_ * p.gyro_denom;
+    p.gyro_period = TWOPI_ * p.gam_pf * mc * p.gyro_denom;
+  }
+  const double vp_tg = TWOPI_ * grt;
+  const double lam = eta * grt;
+  double sn, cs;
+  mcsm::sincos_t(mcsm::sqrt_nn_(fdiv(6 * vp_tg, p.xn_per * lam)), &sn, &cs, kc);
+  p.cm_val = cs;
   p.rp_val = rcp_refined(p.ptot_pf);
 }
 
@@ -871,7 +895,8 @@ __device__ __forceinline__ void load_particle(CK* a, const Hot& h, long long k, 
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
-  p.flags = F_RS | F_RM | F_NOPARK | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0);   // (F_NOPARK: the new particle's first Code Blocks run now)
+  p.flags = F_RS | F_RM | F_NOPARK | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0) |   // (F_NOPARK: the new particle's first Code Blocks run now)
+            ((p.downstream && !p.inj && p.x < 0) ? F_INJCHK : 0);
   p.n_ovr = 0u;
   refresh_time(a, h, p);
   p.npush = 0;
@@ -934,6 +959,22 @@ __device__ __forceinline__ void refresh_dtest(CK* a, const Hot& h, Pt& p) {
     v_fac = gyro_fac * a->P.pe_crit / (m * a->P.game_crit * h.u2);
   } else {
     v_fac = p.gyro_rad_tot * p.ptot_pf / (m * p.gam_pf * h.u2);
+  }
+  const double L_diff = h.eta / 3 * v_fac;
+  const double t1 = 1.1 * p.prp, t2 = 6.91 * L_diff;
+  double t = t1 > t2 ? t1 : t2;
+  if (h.feb_down > 0 && h.feb_down < t) t = h.feb_down;
+  p.x_dt = t;
+}
+
+__device__ __forceinline__ void refresh_dtest_k(const Hot& h, Pt& p, double pe_crit, double game_crit) {
+  const double aa = h.aa, m = aa * MP_;
+  double v_fac;
+  if (aa < 1 && p.ptot_pf < pe_crit) {
+    const double gyro_fac = pe_crit * CC_ * p.gyro_denom;
+    v_fac = fdiv(gyro_fac * pe_crit, m * game_crit * h.u2);
+  } else {
+    v_fac = fdiv(p.gyro_rad_tot * p.ptot_pf, m * p.gam_pf * h.u2);
   }
   const double L_diff = h.eta / 3 * v_fac;
   const double t1 = 1.1 * p.prp, t2 = 6.91 * L_diff;
@@ -1016,6 +1057,9 @@ __device__ __forceinline__ bool move_and_detect(CK* a, const Hot& h, Pt& p, doub
 // (x, x_old) with move_and_detect's own expressions, and a lane that stopped with nothing due just carries on --
 // nothing of a particle changes while it is masked out of the common pass.  (-DMCS_CHECK_THR poisons the weight
 // of a particle whose exact test fires where the thresholds do not: tests then fail loudly.)
+// NO_XN (LOSSY kernel): the fine / coarse switch is decided in line in every pass (gyro_rad_tot changes with the momentum in
+// every pass there), so it is no threshold
+template <bool NO_XN = false>
 __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
   const double x = p.x, inf = __builtin_inf();
   double hi = p.z_hi, lo = p.z_lo;
@@ -1027,8 +1071,8 @@ __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
   hi = x > p.x_dt ? -inf : hi;
   const double hi_f = xg ? -inf : (g < hi ? g : hi);       // fine steps: the switch is due once x > g
   const double lo_c = xg ? (g > lo ? g : lo) : inf;        // coarse steps: due once x <= g
-  p.t_hi = coarse ? hi : hi_f;
-  p.t_lo = coarse ? lo_c : lo;
+  p.t_hi = NO_XN ? hi : (coarse ? hi : hi_f);
+  p.t_lo = NO_XN ? lo : (coarse ? lo_c : lo);
   p.c_gef = p.downstream ? p.z_gef : 0.0;
   p.c_tev = p.downstream ? p.t_ev : inf;
 }
@@ -1113,6 +1157,7 @@ __device__ __forceinline__ int slow_post(CK* a, const Hot& h, Rng& rng, Pt& p, d
     }
     if (p.downstream && p.x < 0) p.inj = true;
   }
+  p.flags &= ~F_INJCHK;      // (either injected now, or at x >= 0, from where x < 0 is reached through the shock: an event)
   TTG_MARK(41);
   {
     // all_flux! (all_flux.jl:45-82): zone search; a tally record only when something was crossed
@@ -1180,8 +1225,11 @@ __device__ __forceinline__ void refresh_move(CK* a, const Hot& h, Pt& p) {
 // Everything before the next scatter (head of the loop body and of Code Block 3,
 // particle_loop.jl:154-326, 361-385).  `t_clock` is the time step of the previous move, which the
 // clock of this pass still uses (particle_loop.jl:350 precedes :400).  Returns the end code or -1.
-__device__ __forceinline__ int slow_pre(CK* a, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock) {
+__device__ __forceinline__ int slow_pre(CK* a, const Hot& h, const mcsm::HotCoef& kc, Rng& rng, Pt& p, double t_clock, const bool lossy = false) {
   const double aa = h.aa;
+  // (LOSSY kernel: the pass that was running lost all momentum in its in-line radiative loss -- the statements below at
+  // `rad_losses`, with the floors already applied and the pass already counted)
+  if (lossy && (p.flags & F_LOST)) return 4;
   if (p.helix >= MCS_HELIX_CAP) {            // the pass about to start would be number cap+1: quirk Q5
     p.helix += 1;
     cnt(a, MCS_IC_HELIX_CAP);
@@ -1543,7 +1591,14 @@ __device__ __forceinline__ void block_flush(CK* a) {
 // no custom eps_B, no energy transfer, no electron radiative losses, no downstream FEB, DSA on with
 // injection probability 1, ions, no x_spec detectors.  The flags are then compile-time constants: their
 // scalar branches and the code behind them disappear from that kernel.
-template <bool PLAIN>
+// LOSSY = electrons with radiative losses (and none of: custom eps_B, no-scatter), decided by the host.  The reference applies
+// the loss in EVERY pass (particle_loop.jl:302-326), and everything derived from the momentum follows: in the general
+// kernel such a configuration visits the rare region in every pass (h.every_pass: one common pass per trip, the whole of
+// slow_pre per pass -- measured 7 000 SIMD cycles per wave-pass against ~1 100 for the common pass).  Here the loss and the
+// refreshes that hang on it are straight-line code at the head of the common pass, for exactly the lanes whose other
+// statements of slow_pre are no-ops (no flag set, nothing pending); a lane that has just run slow_pre in the rare region has
+// had this pass's loss there and skips the block once.  Same statements in the same order on the same values.
+template <bool PLAIN, bool LOSSY = false>
 __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
@@ -1574,6 +1629,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   if (PLAIN) {
     h.custom_epsB = false; h.etf = false; h.dont_scatter = false; h.dont_DSA = false; h.oblique = false;
     h.every_pass = false; h.odd_cfg = false;
+  }
+  // the constants of the in-line loss (LOSSY only; dead code otherwise)
+  double l_bcmb = 0, l_pe_crit = 0, l_game_crit = 0;
+  if (LOSSY) {
+    h.every_pass = false; h.custom_epsB = false; h.dont_scatter = false; h.rad_losses = true;
+    l_bcmb = sconst(a->P.B_CMBz); l_pe_crit = sconst(a->P.pe_crit); l_game_crit = sconst(a->P.game_crit);
   }
 
   // the 29 constants of the per-step sincos + asin, resident in VGPRs
@@ -1711,7 +1772,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if (__builtin_amdgcn_readfirstlane(base >= n ? 1 : 0)) {
           exhausted = true;
           defer_k = 1u;
-          ring_on = __builtin_amdgcn_readfirstlane(a->tail_ring) != 0;
+          ring_on = !LOSSY && __builtin_amdgcn_readfirstlane(a->tail_ring) != 0;     // (LOSSY: the cone changes in every pass)
           mtick_ex = mtick;
           if (mrole != 0 || budget != 0u) mpoll_mask = MCS_MERGE_POLL_MASK;
 #ifdef MCS_PROF_TAIL
@@ -1751,7 +1812,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!active && rank >= b0 && rank < b0 + cb) {
               mb_load(wv, rank - b0, p, rng, k, evw, phi_prev);
-              refresh_thr(h, p);
+              refresh_thr<LOSSY>(h, p);
               act = -1; rb = rng.n - 256u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1767,7 +1828,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const unsigned r = below(idle_now);
         if (!active && r < cntm) {
           mb_load(mpartner, r, p, rng, k, evw, phi_prev);
-          refresh_thr(h, p);
+          refresh_thr<LOSSY>(h, p);
           rb = rng.n - 256u;
           act = -1;
         }
@@ -1873,6 +1934,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     if (rare_any__) tt0__ = __builtin_amdgcn_s_memtime();
 #endif
     bool waits_now = false;
+    bool loss_done = false;         // LOSSY: slow_pre has applied this pass's radiative loss for this lane
     // ---- deferral.  Entering the rare region costs the WAVE ~1000 cycles whatever the number of lanes in it, and in the
     // bulk of a launch some lane has a zone crossing pending in three passes out of four (2.4 lanes per entry): half of
     // all VALU issue went into the region for two or three lanes.  A lane can wait: nothing of its particle changes
@@ -1903,13 +1965,13 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const bool fwd = p.x > p.x_old;
         const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
         const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
-        const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
+        const bool ev_xn = !LOSSY & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));      // (LOSSY: decided in line, after the loss)
         ev_x = thr & !same_zone;
         up_due = thr & ev_up; xn_due = thr & ev_xn;
         ev = ev | up_due | xn_due;
       }
       [[maybe_unused]] const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
-      const bool post_pending = moved && (ev || ev_x || (p.flags & F_NEARFEB) != 0);
+      const bool post_pending = moved && (ev || ev_x || (p.flags & (F_NEARFEB | F_INJCHK)) != 0);
       int end = -1;
       // What is due, from the state the move left (the expressions of move_and_detect).  A lane with nothing but
       // a plain zone crossing, a time cut, a fine/coarse switch or the cos_max refresh that follows one takes the
@@ -1988,7 +2050,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           t_clock = p.t_step;
         }
         TT_MARK(17);
-        if (end < 0) end = slow_pre(a, h, kc, rng, p, t_clock);
+        if (end < 0) { end = slow_pre(a, h, kc, rng, p, t_clock, LOSSY); loss_done = true; }
         TT_MARK(18);
       }
       if (end >= 0) {
@@ -2027,7 +2089,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       }
       // the position thresholds of the common pass, from the state the lane leaves the region with (a waiting lane
       // comes back with its pending move and is refreshed then)
-      if (!waits_now) refresh_thr(h, p);
+      if (!waits_now) refresh_thr<LOSSY>(h, p);
       if (MCS_UNLIKELY(ring_on)) rb = (p.cm_val != cm_in) ? rng.n - 256u : rb;      // the cone changed: this lane's batch is void
     }
     const bool frozen = want & !enter;  // waits for the region: sits out this pass
@@ -2095,6 +2157,48 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       }
       // ---- the common pass, for every lane that is not waiting (idle lanes compute on stale state; nothing is stored)
       PROF_LANES(9, run & active); PROF_ADD(7, 1);
+      if constexpr (LOSSY) {
+        // slow_pre's radiative loss (particle_loop.jl:302-326 -> :578-592) and what hangs on the momentum, for a lane on which
+        // every other statement of slow_pre is a no-op: no flag set (so not near p_max, not to be saved, not in the FEB zone,
+        // zone loaded), nothing pending from the last move (the clock and position events stop a lane before this).  The
+        // momentum only decreases here, so F_NEARP / F_SAVE stay clear; the cone is refreshed with the xn_per of before this
+        // pass's fine / coarse decision, as slow_pre does; t_clock is the time step of the previous move.
+        if (run && !(rep == 0 && loss_done)) {
+          const double bmag = S_bt[p.ig3];
+          const double ptot_old = p.ptot_pf;
+          const double B_CMB_loc = l_bcmb * p.z_gef;
+          double pn;
+          {   // radiation_loss (particle_loop.jl:578-592)
+            const double dlnp = MCS_RAD_LOSS_FAC * (bmag * bmag + B_CMB_loc * B_CMB_loc) * ptot_old * t_clock;
+            if (dlnp > 1.0e-2) pn = fdiv(ptot_old, 1 + dlnp); else pn = ptot_old * (1 - dlnp);
+          }
+          if (MCS_UNLIKELY(pn <= 0)) {
+            // the pass ends here with finish code 4: floors as in slow_pre, the pass counted; slow_pre returns 4 at the next header
+            p.ptot_pf = MCS_FLOOR; p.pb_pf = MCS_FLOOR; p.p_perp = MCS_FLOOR; p.gam_pf = 1;
+            p.helix += 1;
+            p.flags |= F_LOST;
+            run = false;
+          } else {
+            p.ptot_pf = pn;
+            p.gam_pf = mcsm::hypot1(fdiv(p.ptot_pf, h.mc));
+            const double ratio = fdiv(p.ptot_pf, ptot_old);
+            p.pb_pf *= ratio;
+            p.p_perp *= ratio;
+            p.gyro_rad_tot = p.ptot_pf * CC_ * p.gyro_denom;
+            p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
+            refresh_scatter_k(p, kc, h.aa, h.aa * MP_ * CC_, h.eta, l_pe_crit, l_game_crit);
+            refresh_dtest_k(h, p, l_pe_crit, l_game_crit);
+            p.xn_per = p.x > p.gyro_rad_tot ? h.xn_coarse : h.xn_fine;
+            {   // refresh_move
+              const double rx = rcp_refined(p.xn_per);
+              p.dphi = div_r(TWOPI_, p.xn_per, rx);
+              p.t_step = div_r(p.gyro_period, p.xn_per, rx);
+              p.rg_val = rcp_refined(p.gam_pf * (h.aa * MP_));
+            }
+            refresh_thr<true>(h, p);
+          }
+        }
+      }
       if (run) {
         p.helix += 1;
         if (!h.dont_scatter) {
@@ -2147,6 +2251,9 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain(const KArgs* __restrict__ ka) {
   transport_body<true>(ka);
 }
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_lossy(const KArgs* __restrict__ ka) {
+  transport_body<false, true>(ka);
+}
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
@@ -2164,9 +2271,10 @@ extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_gr
 extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 
 // `a_dev`: device copy of the launch constants (written by the caller on `st`).
-// `plain`: the host has checked the conditions of the PLAIN specialisation (see transport_body).
-extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int plain, int blocks, int threads, hipStream_t st) {
-  if (plain) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
+// `kind`: 0 the general kernel; 1 / 2: the host has checked the conditions of the PLAIN / LOSSY specialisation (see transport_body).
+extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st) {
+  if (kind == 1) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 2) hipLaunchKernelGGL(mcs_k_transport_lossy, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
   return hipGetLastError();
 }

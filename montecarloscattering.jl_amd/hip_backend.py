@@ -103,6 +103,10 @@ class HipBackend:
     def last_launches(self) -> int:
         return int(self.lib.mcs_last_launches(self.h))
 
+    def last_kernel(self) -> int:
+        """0 general, 1 plain, 2 lossy, 3 fp32, 4 fp32 plain loop (mcs_last_kernel)"""
+        return int(self.lib.mcs_last_kernel(self.h))
+
     # -- per iteration / species
     def begin_iteration(self, i_iter):
         self._chk(self.lib.mcs_begin_iteration(self.h, i_iter))

@@ -468,6 +468,72 @@ def test_specialised_and_general_kernel_agree(monkeypatch):
     assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
 
 
+@pytest.mark.parametrize("case", ["crafted", "thermal_mixed"])
+def test_lossy_kernel_agrees_with_general_and_oracle(monkeypatch, case):
+    """Electrons with radiative losses run mcs_k_transport_lossy: the loss of every pass (particle_loop.jl:302-326) and the
+    refreshes that hang on the momentum in line in the common pass, where the general kernel visits the rare region in every
+    pass (MCS_FORCE_GENERAL=1).  Same statements on the same values: particles and integer tallies identical between the two
+    kernels and the oracle.  `crafted`: the hand-placed relativistic electrons of the golden case electrons_crafted_n64 at 4096
+    particles (strong field: losses that matter, the constant-mfp branch below p_e,crit, PRP shortening, retro walks with
+    losses, zero-energy exits); `thermal_mixed`: the electron species of the p + e- configuration of the golden case mixed_n96
+    (x_spec detectors, injection probability < 1, energy transfer)."""
+    from golden_common import make_golden
+    name = "electrons_crafted_n64" if case == "crafted" else "mixed_n96"
+    spec = make_golden.CASES[name]
+    kw = dict(spec["cfg"])
+    kw["species"] = [mcs.inputs.Species(**sp) for sp in kw["species"]]
+    xs_rg = kw.pop("XSPEC_rg", None)
+    N = 4096
+    def build():
+        cfg = mcs.inputs.Config(N_PTS_INJ=N, N_PTS_PCUT=N, N_PTS_PCUT_HI=N, **kw)
+        if xs_rg is not None:
+            cfg.XSPEC = tuple(x * mcs.inputs.build_problem(cfg).rg0 for x in xs_rg)
+        return mcs.inputs.build_problem(cfg)
+    i_ion = len(kw["species"])          # the electrons
+    def run(backend, prob):
+        cfg = prob.cfg; sp = cfg.species[i_ion - 1]
+        backend.begin_iteration(1)
+        inj = mcs.inputs.init_pop_host(prob, i_ion)
+        pmax = mcs.inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
+        backend.begin_species(1, i_ion, sp.aa, abs(sp.zz), pmax, sp.density, 1.0 / cfg.species[-1].density)
+        backend.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+        if case == "crafted": backend.set_population(make_golden.crafted_population("electrons", prob, N))
+        else: backend.init_pop(inj, 0, inj.n_pts_use, inj.n_pts_use)
+        fin = []
+        for ip in range(1, 5):
+            n = backend.pop_size()
+            ns = backend.run_pcut(ip, 0)
+            fin.append((backend.finals(), backend.get_saved()))
+            if ns == 0: break
+            backend.new_pcut(max(n // ns, 1))
+        return fin, backend.read_tallies()
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MCS_FORCE_GENERAL", force)
+        prob = build()
+        hb = hip_backend(prob)
+        out.append(run(hb, prob))
+        assert hb.last_kernel() == (2 if force == "0" else 0)
+        L = hb.layout
+        hb.destroy()
+    prob = build()
+    ob = oracle_backend(prob, nthreads=16)
+    out.append(run(ob, prob))
+    ob.destroy()
+    (fa, (Ta, Ia)) = out[0]
+    IC, ng = mcs.capi.IC, prob.n_grid
+    assert int(Ia[ng + IC["STEPS_HELIX"]]) > 100 * N          # (the losses run in the helix loop, not in a plumbing case)
+    for which, (fb, (Tb, Ib)) in (("general kernel", out[1]), ("oracle", out[2])):
+        assert len(fa) == len(fb)
+        for ip, ((xa, (sa, la)), (xb, (sb, lb))) in enumerate(zip(fa, fb), 1):
+            for k in xa:
+                assert np.array_equal(bits(xa[k]), bits(xb[k])), f"lossy kernel vs {which}: pcut {ip}, {k}"
+            assert np.array_equal(la, lb)
+            assert_pop_equal(sa, sb, f"saved arrays, lossy kernel vs {which}, pcut {ip}")
+        assert np.array_equal(Ia, Ib), which
+        assert_tallies_close(L, Ta, Tb, TALLY_RTOL)
+
+
 def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
     """K1 reorders work: a lane that needs the full Code Blocks waits (F_WAIT) until the next refill releases the
     batch (MCS_PARK; round 1 parked the particle in global memory), several common passes run per trip through the loop
