@@ -85,3 +85,53 @@ def assert_tallies_close(L, Ta, Tb, rtol=1e-11):
             continue
         err = float(np.max(np.abs(a - b))) / scale
         assert err <= rtol, f"tally {name}: max|diff|/max|ref| = {err:.3e} > {rtol}"
+
+
+def fuzz_population(prob, N, seed, aa):
+    """A caller's own population: every combination of the state bits (downstream, inj), positions all over the grid -- far
+    upstream beyond the FEB, within 1e-7 r_g of the shock on either side, downstream of x_grid_stop --, momenta over six
+    decades, the PRP on either side of the particle, ages around age_max, every time-cut index, both step sizes.  States the
+    path itself never produces (e.g. downstream-flagged, not injected, at x < 0) are legal inputs of mcs_pop_upload."""
+    rng = np.random.default_rng(seed)
+    pop = mcs.capi.Population(N)
+    mc = aa * mcs.constants.MP * mcs.constants.C
+    pop.ptot_pf[:] = mc * 10 ** rng.uniform(-3.0, 3.5, N)
+    pop.pb_pf[:] = pop.ptot_pf * rng.uniform(-1, 1, N)
+    pop.weight[:] = rng.uniform(0.5, 1.5, N) / N
+    xg = prob.x_grid_cm
+    far = rng.random(N) < 0.5
+    x_rg = np.where(far, rng.uniform(-150, 50, N), rng.choice([-1.0, 1.0], N) * 10 ** rng.uniform(-7, 0, N))
+    x = np.maximum(x_rg * prob.rg0, xg[1] * 0.999)          # (downstream of x_grid_stop is a valid place: the last zone)
+    pop.x_PT_cm[:] = x
+    pop.grid[:] = np.searchsorted(xg, x, side="right") - 1
+    pop.downstream[:] = rng.random(N) < 0.6
+    pop.inj[:] = rng.random(N) < 0.4
+    pop.xn_per[:] = np.where(rng.random(N) < 0.5, prob.params.xn_per_fine, prob.params.xn_per_coarse)
+    pop.prp_x_cm[:] = np.where(rng.random(N) < 0.5, prob.params.x_grid_stop, np.abs(x) * 10 ** rng.uniform(-1, 1, N))
+    pop.acctime_sec[:] = np.where(rng.random(N) < 0.3, 0.0, 10 ** rng.uniform(0, 9, N))
+    old = rng.random(N) < 0.1
+    pop.acctime_sec[old] = 10 ** rng.uniform(11, 12.5, int(old.sum()))          # around age_max
+    pop.phi_rad[:] = rng.uniform(0, 2 * np.pi, N)
+    nt = len(prob.tcuts)
+    pop.tcut[:] = rng.integers(1, max(nt, 1) + 2, N) if nt else 1
+    return pop
+
+
+def fuzz_problem(kind, N):
+    """The four configurations of the fuzzed-population runs: (problem, aa of its first species)."""
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    kw, aa = {}, 1.0
+    if kind == "general":
+        kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)], energy_transfer_frac=0.1,
+                  FEB_downstream=(30.0, 0.0), INJFR=[0.7, 1.0], maximum_energy=(0.0, 0.0, 1e3))
+    elif kind == "electrons":
+        kw = dict(species=[mcs.inputs.Species(me_mp, -1.0, 1e6, 1.0)], radiation_losses=True, B_mag_upstream=3.0, b_field_turbulence=1.0,
+                  electron_energy_mfp_threshold=1e4, B_CMBz=1e-3)
+        aa = me_mp
+    prob = make_problem(N, **kw)
+    if kind == "oblique":
+        xg, up = prob.x_grid_cm, prob.x_grid_cm < 0
+        ux = prob.ux.copy(); ux[up] = prob.ux[1] * (1 - 0.3 * np.exp(xg[up] / (50.0 * prob.rg0))); prob.ux = ux      # a precursor
+        prob.theta = np.where(xg < 0, 0.35, 0.8); prob.uz = 0.05 * prob.ux; prob.utot = np.hypot(prob.ux, prob.uz)
+        prob.gam_sf = 1 / np.sqrt(1 - (prob.utot / mcs.constants.C) ** 2)
+    return prob, aa

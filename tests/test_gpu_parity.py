@@ -534,6 +534,54 @@ def test_lossy_kernel_agrees_with_general_and_oracle(monkeypatch, case):
         assert_tallies_close(L, Ta, Tb, TALLY_RTOL)
 
 
+@pytest.mark.parametrize("kind", ["protons", "general", "electrons", "oblique"])
+def test_fuzzed_caller_populations_vs_oracle(kind):
+    """mcs_pop_upload takes any population, not only the ones the path produces: 8192 random particles (conftest.fuzz_population --
+    every combination of downstream / inj, positions from beyond the upstream FEB to downstream of x_grid_stop and within 1e-7
+    r_g of the shock, six decades of momentum, the PRP on either side, ages around age_max, every time-cut index) through three
+    pcuts on the GPU and on the oracle.  `protons`: the plain kernel; `general`: p + He, energy transfer, downstream FEB, injection
+    probability 0.7, a low p_max; `electrons`: radiative losses in a strong field, the lossy kernel; `oblique`: a precursor profile
+    with an oblique field.  All four finish reasons occur.  Particles, saved arrays and integer tallies bit for bit, binned
+    tallies to 1e-11.  (This is the test that would have found the `inj` update missing after the first move of a
+    downstream-flagged particle loaded at x < 0: DESIGN.md section 3.)"""
+    from conftest import fuzz_population, fuzz_problem
+    N = 8192
+    prob, aa = fuzz_problem(kind, N)
+    pop = fuzz_population(prob, N, 1, aa)
+    assert int(((pop.downstream == 1) & (pop.inj == 0) & (pop.x_PT_cm < 0)).sum()) > 100
+    sp = prob.cfg.species[0]
+    inj = mcs.inputs.init_pop_host(prob, 1)
+    pmax = mcs.inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
+    def run(be):
+        be.begin_iteration(1)
+        be.begin_species(1, 1, sp.aa, abs(sp.zz), pmax, sp.density, 1.0)
+        be.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+        be.set_population(pop)
+        out = []
+        for ip in range(2, 5):
+            n = be.pop_size()
+            ns = be.run_pcut(ip, 0)
+            out.append((be.finals(), be.get_saved()))
+            if ns == 0: break
+            be.new_pcut(max(n // ns, 1))
+        return out, be.read_tallies()
+    hb, ob = hip_backend(prob), oracle_backend(prob, nthreads=16)
+    (fa, (Ta, Ia)), (fb, (Tb, Ib)) = run(hb), run(ob)
+    assert hb.last_kernel() == {"protons": 1, "general": 0, "electrons": 2, "oblique": 0}[kind]
+    reasons = np.zeros(5, dtype=np.int64)
+    assert len(fa) == len(fb)
+    for ip, ((xa, (sa, la)), (xb, (sb, lb))) in enumerate(zip(fa, fb), 2):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), f"{kind}: pcut {ip}, {k}"
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, f"{kind}: saved arrays, pcut {ip}")
+        reasons += np.bincount(xa["reason"], minlength=5)[:5]
+    assert np.all(reasons[:4] > 0), reasons
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(hb.layout, Ta, Tb, TALLY_RTOL)
+    hb.destroy(); ob.destroy()
+
+
 def test_parking_and_tail_consolidation_do_not_change_results(monkeypatch):
     """K1 reorders work: a lane that needs the full Code Blocks waits (F_WAIT) until the next refill releases the
     batch (MCS_PARK; round 1 parked the particle in global memory), several common passes run per trip through the loop

@@ -252,3 +252,23 @@ def test_crafted_electrons_losses_and_prp_shortening():
     _compare_species(prob, ob, tw, bases, pop, 2, N)
     assert tw.cnt["REASON4"] + tw.cnt["HELIX_CAP"] + tw.cnt["STEPS_RETRO"] > 0
     ob.destroy()
+
+
+@pytest.mark.parametrize("kind", ["protons", "electrons"])
+def test_fuzzed_caller_populations_oracle_vs_twin(kind):
+    """The random caller-provided populations of the GPU test test_fuzzed_caller_populations_vs_oracle (conftest.fuzz_population:
+    every combination of downstream / inj, positions from beyond the upstream FEB to downstream of x_grid_stop, the PRP on either
+    side, ages around age_max, every time-cut index), 40 particles, through the oracle and the twin: the oracle is right about
+    the states the path itself never produces -- e.g. the `inj` update after the first move of a downstream-flagged particle
+    loaded at x < 0 (particle_loop.jl:433-435), which the HIP path once missed."""
+    from conftest import fuzz_population, fuzz_problem
+    N = 40
+    prob, aa = fuzz_problem(kind, N)
+    ob = oracle_backend(prob, math="libm", nthreads=1)
+    tw, *bases = _begin_species(prob, ob, 1, True)
+    pop_full = fuzz_population(prob, N, 1, aa)
+    assert int(((pop_full.downstream == 1) & (pop_full.inj == 0) & (pop_full.x_PT_cm < 0)).sum()) >= 3
+    pop = {f: getattr(pop_full, f).copy() for f in FIELDS}
+    _compare_species(prob, ob, tw, bases, pop, 2, N, first_pcut=2)
+    assert tw.cnt["REASON1"] > 0 and tw.cnt["REASON2"] + tw.cnt["REASON3"] > 0
+    ob.destroy()
