@@ -985,3 +985,49 @@ def test_fp32_kernels_agree(monkeypatch, case):
         assert_pop_equal(sa, sb, f"ion {ia} pcut {pa}: saved arrays")
     assert np.array_equal(Ia, Ib)
     assert_tallies_close(mcs.capi.Layout(prob.params), Tb, Ta, TALLY_RTOL)
+
+
+@pytest.mark.parametrize("kind", ["protons", "general", "electrons", "oblique"])
+def test_fp32_kernels_agree_on_fuzzed_caller_populations(monkeypatch, kind):
+    """The two forms of the fp32-state variant (plain loop / organised like K1) on the random caller-provided populations of
+    test_fuzzed_caller_populations_vs_oracle: the plain loop runs the `inj` update, the exit tests and the zone reload in every
+    pass as the reference writes them, the organised kernel only where its flags and events say so -- they must agree bit for
+    bit on states the path never produces too."""
+    from conftest import fuzz_population, fuzz_problem
+    N = 8192
+    res = []
+    for loop in ("1", "0"):
+        monkeypatch.setenv("MCS_F32_LOOP", loop)
+        prob, aa = fuzz_problem(kind, N)
+        prob.params.state_fp32 = 1
+        pop = fuzz_population(prob, N, 1, aa)
+        sp = prob.cfg.species[0]
+        inj = mcs.inputs.init_pop_host(prob, 1)
+        pmax = mcs.inputs.get_pmax_cutoff(prob.Emax_keV, prob.Emax_per_aa_keV, prob.pmax, sp.aa)
+        hb = hip_backend(prob)
+        hb.begin_iteration(1)
+        hb.begin_species(1, 1, sp.aa, abs(sp.zz), pmax, sp.density, 1.0)
+        hb.set_fluxes(inj.pxx_flux, inj.pxz_flux, inj.energy_flux)
+        hb.set_population(pop)
+        out = []
+        for ip in range(2, 5):
+            n = hb.pop_size()
+            ns = hb.run_pcut(ip, 0)
+            out.append((hb.finals(), hb.get_saved()))
+            if ns == 0: break
+            hb.new_pcut(max(n // ns, 1))
+        assert hb.last_kernel() == (4 if loop == "1" else 3)
+        res.append((out, hb.read_tallies(), hb.layout))
+        hb.destroy()
+    (fa, (Ta, Ia), L), (fb, (Tb, Ib), _) = res
+    assert len(fa) == len(fb)
+    reasons = np.zeros(5, dtype=np.int64)
+    for ip, ((xa, (sa, la)), (xb, (sb, lb))) in enumerate(zip(fa, fb), 2):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), f"{kind}: pcut {ip}, {k} differs for {(xa[k] != xb[k]).sum()} particles"
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, f"{kind}: saved arrays, pcut {ip}")
+        reasons += np.bincount(xa["reason"], minlength=5)[:5]
+    assert np.all(reasons[:3] > 0), reasons
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(L, Ta, Tb, TALLY_RTOL)
