@@ -18,7 +18,7 @@ extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
-hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int loop, int blocks, int threads, hipStream_t st);
+hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
 hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st);
@@ -699,12 +699,12 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
-  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : 3) : (plain ? 1 : (lossy ? 2 : 0));
+  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (plain ? 1 : (lossy ? 2 : 0));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
-      if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : 0, blocks, 256, c->stream));
+      if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : (lossy ? 2 : 0), blocks, 256, c->stream));
       else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : (lossy ? 2 : 0), blocks, threads, c->stream));
       c->rep_dirty = true;
     }
