@@ -119,9 +119,24 @@ def workload_label(args):
         head = "non-headline size: "
     profile = ("shock profile replaced after every iteration (smooth_grid_par; every zone crossing takes the frame transform)"
                if args.smooth else "single unmodified gamma0=5 shock")
-    return (f"{head}{size} protons per GPU, {profile}, 45 stock pcuts, scattering+DSA on, fp64; one step = one full iteration "
-            f"(init_pop, 45 x (transport + new_pcut), tally merge [{args.species_tallies} read-back per species], ion_finalize consumers, "
+    what = "protons"
+    if args.mixed:
+        head = "BASELINE config[4]'s species mix: "
+        what = "particles of each of protons, He (density 0.1) and electrons (radiative losses on, ion -> electron energy transfer 0.1)"
+    prec = "fp32 particle state (the fp32-state variant; tallies fp64)" if args.fp32 else "fp64"
+    if args.fp32 and not args.mixed:
+        head = "fp32-state variant of " + head
+    return (f"{head}{size} {what} per GPU, {profile}, 45 stock pcuts, scattering+DSA on, {prec}; one step = one full iteration "
+            f"(per species: init_pop, 45 x (transport + new_pcut), tally merge [{args.species_tallies} read-back per species], ion_finalize consumers; "
             f"iter_finalize" + (" + profile update" if args.smooth else "") + ")")
+
+
+def kernel_label(args):
+    if args.fp32:
+        return "mcs_k_transport_f32" + (" (ions) + mcs_k_transport_f32_lossy (electrons)" if args.mixed else "") + ": the fp32-state variant; priced against the fp64 peak by the same 400-flop weight"
+    if args.mixed:
+        return "mcs_k_transport (ions: energy transfer on) + mcs_k_transport_lossy (electrons with radiative losses); all launches of the timed region"
+    return "mcs_k_transport_plain (the specialisation of mcs_k_transport for this configuration)"
 
 
 def main():
@@ -138,6 +153,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=2,
                     help="extra leg, reported beside `value` and never in it: this many independent iterations in flight (driver.run_overlapped); 1 = skip")
     ap.add_argument("--smooth", action="store_true", help="replace the shock profile after every iteration (smooth_grid_par): config[2]'s loop")
+    ap.add_argument("--mixed", action="store_true", help="BASELINE config[4]'s species mix: protons + He + electrons, radiative losses, ion -> electron energy transfer (--particles per species)")
+    ap.add_argument("--fp32", action="store_true", help="the fp32-state variant of the transport kernel (config[4]); tallies stay fp64")
     args = ap.parse_args()
 
     import torch
@@ -174,8 +191,15 @@ def main():
     n_global = args.particles * world
     n_itrs = args.steps + args.warmup
     # (room in the per-iteration tallies for the iterations of the extra overlapped leg, which carry on the numbering)
-    n_extra = (2 * args.overlap + args.steps) if (world == 1 and not force_comm and args.overlap > 1 and not args.smooth) else 0
-    cfg = mcs.inputs.Config(N_PTS_INJ=n_global, N_PTS_PCUT=n_global, N_PTS_PCUT_HI=n_global, num_iterations=n_itrs + n_extra)
+    overlap_leg = world == 1 and not force_comm and args.overlap > 1 and not args.smooth and not args.mixed and not args.fp32
+    n_extra = (2 * args.overlap + args.steps) if overlap_leg else 0
+    kw = {}
+    if args.mixed:
+        me_mp = mcs.constants.ME / mcs.constants.MP
+        kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.2)],
+                  energy_transfer_frac=0.1, radiation_losses=True)
+    cfg = mcs.inputs.Config(N_PTS_INJ=n_global, N_PTS_PCUT=n_global, N_PTS_PCUT_HI=n_global, num_iterations=n_itrs + n_extra,
+                            state_fp32=args.fp32, **kw)
     prob = mcs.inputs.build_problem(cfg)
     be = hip_backend.HipBackend(local, torch_tallies=world > 1 or force_comm)
     be.create(prob)
@@ -250,14 +274,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32 particle state, f64 tallies" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": workload_label(args),
                        "particles_per_gpu": args.particles, "particles_total": n_global, "species_tallies": args.species_tallies,
                        "steps_per_iteration": steps_total / args.steps,
                        "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 8 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "mcs_k_transport_plain (the specialisation of mcs_k_transport for this configuration)", "launches": n_launch,
+                         "kernel": kernel_label(args), "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                          "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "
@@ -270,7 +294,7 @@ def main():
                                "note": "largest local population / mean, per pcut (1.0 = perfectly balanced)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample, n_sample_1t=args.cpu_sample_1t)
-        if world == 1 and not force_comm and args.overlap > 1 and not args.smooth:
+        if overlap_leg:
             out["overlapped_iterations"] = overlapped_leg(mcs, hip_backend, prob, be, local, args)
         print(json.dumps(out), flush=True)
     if dist is not None:
