@@ -135,7 +135,7 @@ def kernel_label(args):
     if args.fp32:
         return "mcs_k_transport_f32" + (" (ions) + mcs_k_transport_f32_lossy (electrons)" if args.mixed else "") + ": the fp32-state variant; priced against the fp64 peak by the same 400-flop weight"
     if args.mixed:
-        return "mcs_k_transport (ions: energy transfer on) + mcs_k_transport_lossy (electrons with radiative losses); all launches of the timed region"
+        return "mcs_k_transport_plain_etf (ions: energy transfer on) + mcs_k_transport_lossy (electrons with radiative losses); all launches of the timed region"
     return "mcs_k_transport_plain (the specialisation of mcs_k_transport for this configuration)"
 
 

@@ -351,7 +351,7 @@ int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
  * mcs_last_launches: launches the last mcs_run_pcut* took.
  * mcs_last_kernel: which transport kernel they ran -- 0 the general kernel, 1 its specialisation for the common configuration,
  * 2 the one for electrons with radiative losses, 3 the fp32-state kernel, 4 its plain-loop form, 5 its specialisation for
- * electrons with radiative losses. */
+ * electrons with radiative losses, 6 the common configuration with ion -> electron energy transfer on. */
 int mcs_set_tail_slicing(mcs_ctx* ctx, int budget_trips);
 int mcs_last_launches(mcs_ctx* ctx);
 int mcs_last_kernel(mcs_ctx* ctx);

@@ -692,20 +692,21 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   }
   if (budget > 0 && (long long)blocks * threads > c->strag_cap) return fail("mcs_run_pcut: launch geometry exceeds the export buffer of a sliced run");
   // the specialised kernel for the common configuration (see transport_body<PLAIN> in mcs_transport.hip)
-  const bool plain = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
-                     !(c->P.energy_transfer_frac > 0) && !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 &&
-                     c->tb.n_xspec == 0 && !(a.inj_frac < 1);
+  const bool plain_but_etf = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
+                             !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 && c->tb.n_xspec == 0 && !(a.inj_frac < 1);
+  const bool plain = plain_but_etf && !(c->P.energy_transfer_frac > 0);
+  const bool plain_etf = plain_but_etf && !plain;      // the ions of a run with energy transfer: PLAIN with that one flag at run time
   // the specialised kernel for electrons with radiative losses (transport_body<false, LOSSY>): the loss in line in the common pass
   const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
-  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (plain ? 1 : (lossy ? 2 : 0));
+  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
       if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : (lossy ? 2 : 0), blocks, 256, c->stream));
-      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : (lossy ? 2 : 0), blocks, threads, c->stream));
+      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)), blocks, threads, c->stream));
       c->rep_dirty = true;
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));

@@ -1598,7 +1598,8 @@ __device__ __forceinline__ void block_flush(CK* a) {
 // refreshes that hang on it are straight-line code at the head of the common pass, for exactly the lanes whose other
 // statements of slow_pre are no-ops (no flag set, nothing pending); a lane that has just run slow_pre in the rare region has
 // had this pass's loss there and skips the block once.  Same statements in the same order on the same values.
-template <bool PLAIN, bool LOSSY = false>
+// PLAIN_ETF: the PLAIN conditions with the ion -> electron energy transfer left as a run-time flag (the ions of a multi-species run)
+template <bool PLAIN, bool LOSSY = false, bool PLAIN_ETF = false>
 __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
@@ -1627,7 +1628,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   h.every_pass = h.custom_epsB || (h.rad_losses && h.aa < 1) || h.dont_scatter;
   h.odd_cfg = h.feb_down > 0 || h.dont_DSA || h.inj_frac < 1 || h.aa < 1 || h.n_xspec != 0;
   if (PLAIN) {
-    h.custom_epsB = false; h.etf = false; h.dont_scatter = false; h.dont_DSA = false; h.oblique = false;
+    h.custom_epsB = false; h.etf = PLAIN_ETF ? h.etf : false; h.dont_scatter = false; h.dont_DSA = false; h.oblique = false;
     h.every_pass = false; h.odd_cfg = false;
   }
   // the constants of the in-line loss (LOSSY only; dead code otherwise)
@@ -2254,6 +2255,9 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_lossy(const KArgs* __restrict__ ka) {
   transport_body<false, true>(ka);
 }
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain_etf(const KArgs* __restrict__ ka) {
+  transport_body<true, false, true>(ka);
+}
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
@@ -2271,10 +2275,11 @@ extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_gr
 extern "C" int mcs_transport_max_entries(void) { return MCS_MAXNE; }
 
 // `a_dev`: device copy of the launch constants (written by the caller on `st`).
-// `kind`: 0 the general kernel; 1 / 2: the host has checked the conditions of the PLAIN / LOSSY specialisation (see transport_body).
+// `kind`: 0 the general kernel; 1 / 2 / 6: the host has checked the conditions of the PLAIN / LOSSY / PLAIN_ETF specialisation (see transport_body).
 extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st) {
   if (kind == 1) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 2) hipLaunchKernelGGL(mcs_k_transport_lossy, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 6) hipLaunchKernelGGL(mcs_k_transport_plain_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
   return hipGetLastError();
 }

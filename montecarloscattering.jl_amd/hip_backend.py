@@ -104,7 +104,7 @@ class HipBackend:
         return int(self.lib.mcs_last_launches(self.h))
 
     def last_kernel(self) -> int:
-        """0 general, 1 plain, 2 lossy, 3 fp32, 4 fp32 plain loop, 5 fp32 lossy (mcs_last_kernel)"""
+        """0 general, 1 plain, 2 lossy, 3 fp32, 4 fp32 plain loop, 5 fp32 lossy, 6 plain with energy transfer (mcs_last_kernel)"""
         return int(self.lib.mcs_last_kernel(self.h))
 
     # -- per iteration / species

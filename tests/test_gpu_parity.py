@@ -441,11 +441,15 @@ def test_edge_cases_and_errors():
     hb.destroy()
 
 
-def test_specialised_and_general_kernel_agree(monkeypatch):
-    """The common configuration runs mcs_k_transport_plain (compile-time flags); MCS_FORCE_GENERAL=1 keeps
-    the general kernel.  Same problem through both: identical particles, identical integer tallies."""
+@pytest.mark.parametrize("case", ["plain", "plain_etf"])
+def test_specialised_and_general_kernel_agree(monkeypatch, case):
+    """The common configuration runs mcs_k_transport_plain (compile-time flags), the same with ion -> electron energy transfer
+    on (the ions of a multi-species run) mcs_k_transport_plain_etf; MCS_FORCE_GENERAL=1 keeps the general kernel.  Same problem
+    through both: identical particles, identical integer tallies."""
     N = 4000
-    prob = make_problem(N)
+    kw = {} if case == "plain" else dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)],
+                                         energy_transfer_frac=0.1, radiation_losses=True)
+    prob = make_problem(N, **kw)
     out = []
     for force in ("0", "1"):
         monkeypatch.setenv("MCS_FORCE_GENERAL", force)
@@ -457,6 +461,7 @@ def test_specialised_and_general_kernel_agree(monkeypatch):
             fin.append((hb.finals(), hb.get_saved()))
             hb.new_pcut(max(N // ns, 1))
         out.append((fin, hb.read_tallies()))
+        assert hb.last_kernel() == (0 if force == "1" else (1 if case == "plain" else 6))
         hb.destroy()
     (fa, (Ta, Ia)), (fb, (Tb, Ib)) = out
     for (xa, (sa, la)), (xb, (sb, lb)) in zip(fa, fb):

@@ -18,6 +18,7 @@ LIMITS = {
     "mcs_k_transport_plain": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
     "mcs_k_transport": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
     "mcs_k_transport_lossy": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
+    "mcs_k_transport_plain_etf": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
     "mcs_k_transport_f32": dict(vgprs=168, vgpr_spill=64, scratch=512, occupancy=3, lds=54613),
     "mcs_k_transport_f32_lossy": dict(vgprs=168, vgpr_spill=64, scratch=512, occupancy=3, lds=54613),
     "mcs_k_transport_f32_loop": dict(vgprs=128, vgpr_spill=0, scratch=256, occupancy=4, lds=40960),
