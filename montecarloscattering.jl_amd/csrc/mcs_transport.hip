@@ -199,7 +199,8 @@ __shared__ unsigned int S_evcur[4];         // per-wave stack height
 #define F_ZONE    0x004   // i_grid != ig3: Code Block 3 has to reload the zone (particle_loop.jl:186-246)
 #define F_B1      0x008   // next pass is Code Block 1 (i_return == 1 after a PRP return, particle_loop.jl:167-177)
 #define F_NEARP   0x010   // ptot_pf > pmax_cutoff: the p_max exit needs its transform (particle_loop.jl:264)
-#define F_NEARFEB 0x020   // i_grid <= i_grid_feb: FEB exit test and all_flux's upstream special case every pass
+#define F_NEARFEB 0x020   // (fp32 kernel only) i_grid <= i_grid_feb: FEB exit test and all_flux's upstream special case every pass.  The fp64 kernel
+                          // does not set it since round 3: see `near_feb` in refresh_thr
 #define F_SAVE    0x040   // downstream && ptot_pf > pcut: saved for the next pcut at the next Code Block 3
 #define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
 #define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
@@ -895,7 +896,7 @@ __device__ __forceinline__ void load_particle(CK* a, const Hot& h, long long k, 
   p.gyro_rad = p.p_perp * CC_ * p.gyro_denom;
   p.x_old = 0.0;
   p.cm_val = 0.0; p.rp_val = 0.0; p.rg_val = 0.0; p.x_dt = __builtin_inf();
-  p.flags = F_RS | F_RM | F_NOPARK | (p.i_grid <= h.i_grid_feb ? F_NEARFEB : 0) |   // (F_NOPARK: the new particle's first Code Blocks run now)
+  p.flags = F_RS | F_RM | F_NOPARK |   // (F_NOPARK: the new particle's first Code Blocks run now)
             ((p.downstream && !p.inj && p.x < 0) ? F_INJCHK : 0);
   p.n_ovr = 0u;
   refresh_time(a, h, p);
@@ -1067,6 +1068,17 @@ __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
   const bool b1 = x < T1, b2 = x < T2, coarse = p.xn_per == h.xn_coarse, xg = x > g;
   hi = (b1 & (T1 < hi)) ? T1 : hi;   lo = (!b1 & (T1 > lo)) ? T1 : lo;
   hi = (b2 & (T2 < hi)) ? T2 : hi;   lo = (!b2 & (T2 > lo)) ? T2 : lo;
+  {
+    // The zones up to i_grid_feb (the upstream free-escape boundary lies INSIDE zone i_grid_feb).  The reference gives them two
+    // things in every pass: all_flux! does not return early there (all_flux.jl:74-82) -- which, while the particle stays in its
+    // zone, tallies nothing (F_stream!'s zone range is empty) except the two escape scalars when an injected particle passes
+    // the boundary (all_flux.jl:150-160) --, and Code Block 3 ends an injected particle beyond it (particle_loop.jl:266-275).
+    // Both need `inj` and x < feb_upstream: one more downward threshold instead of a visit to the rare region in every pass
+    // (`inj` changes in rare code only, where this is refreshed).
+    const double T3 = h.feb_up;
+    const bool near_feb = (p.i_grid <= h.i_grid_feb) & p.inj & (x >= T3);
+    lo = (near_feb & (T3 > lo)) ? T3 : lo;
+  }
   hi = p.x_dt < hi ? p.x_dt : hi;
   hi = x > p.x_dt ? -inf : hi;
   const double hi_f = xg ? -inf : (g < hi ? g : hi);       // fine steps: the switch is due once x > g
@@ -1206,7 +1218,6 @@ __device__ __forceinline__ int slow_post(CK* a, const Hot& h, Rng& rng, Pt& p, d
   if (i_return == 1) f |= F_B1;
   if (p.i_grid != i_grid_before) f |= F_CROSSED; else f &= ~F_CROSSED;
   if (p.i_grid != p.ig3) f |= F_ZONE;
-  f = p.i_grid <= h.i_grid_feb ? (f | F_NEARFEB) : (f & ~F_NEARFEB);
   p.flags = f;
   refresh_time(a, h, p);
   refresh_dtest(a, h, p);      // prp may have moved (shock crossing, PRP logic)
@@ -1921,7 +1932,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     }
     double t_clock = p.t_step;      // the clock of a pass uses the time step of the PREVIOUS move
     // ---- the one rare region (see the comment above move_and_detect)
-    // (ev and ev_x are false for a particle that has not moved yet; F_NEARFEB is one of the flags)
+    // (ev and ev_x are false for a particle that has not moved yet)
     // (| and &: one condition, one conditional region -- && / || compile to nested exec-mask regions)
     // (pending-move bits and flags in one test; bits 0-1 of evw are clear for a particle that has not moved yet)
     // (the helix cap is reported through the ev bit by the common pass, see below)
@@ -1941,12 +1952,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // all VALU issue went into the region for two or three lanes.  A lane can wait: nothing of its particle changes
     // while it is masked out of the common pass (state, RNG stream position and pending-event bits stay as they are), so
     // its history -- every bit of it -- is the same whenever the region is finally entered.  The wave therefore enters
-    // only when MCS_DEFER_K lanes have work pending, or one that must not wait (a lane that needs the region in every
-    // pass -- the FEB zone -- or that has just been loaded or resumed, F_NOPARK); the waiting lanes sit out the common pass.
+    // only when MCS_DEFER_K lanes have work pending, or one that must not wait (a lane that has just been loaded or resumed,
+    // F_NOPARK); the waiting lanes sit out the common pass.
     // After the work counter is exhausted nothing waits (defer_k = 1): the launch then waits for its longest histories;
     // configurations with work in every pass (h.every_pass) never wait either.
     const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want);
-    const unsigned long long m_urgent = __builtin_amdgcn_ballot_w64(want & ((wi & (F_NEARFEB | F_NOPARK)) != 0));
+    const unsigned long long m_urgent = __builtin_amdgcn_ballot_w64(want & ((wi & F_NOPARK) != 0));
     const bool enter = (m_urgent != 0ull) | ((unsigned)__popcll(m_want) >= defer_k);
     if (MCS_UNLIKELY(want & enter)) {      // (one condition, one conditional region: `enter` is wave-uniform)
       PROF_ADD(12, 1);
@@ -1961,7 +1972,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       const double cm_in = p.cm_val;          // (a batch of the tail ring is built on it: compared at the end of the region)
       const bool moved = (evw & 4) != 0, thr = (evw & 2) != 0;
       bool ev = (evw & 1) != 0, ev_x = false;
-      bool up_due = false, xn_due = false;    // the upward thresholds / the fine-coarse switch of move_and_detect: they imply `thr`
+      bool up_due = false, xn_due = false, feb_due = false;    // the upward thresholds / the fine-coarse switch of move_and_detect / the upstream FEB: they imply `thr`
       if (__builtin_amdgcn_ballot_w64(thr) != 0ull) {
         const bool fwd = p.x > p.x_old;
         const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
@@ -1969,10 +1980,13 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         const bool ev_xn = !LOSSY & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));      // (LOSSY: decided in line, after the loss)
         ev_x = thr & !same_zone;
         up_due = thr & ev_up; xn_due = thr & ev_xn;
-        ev = ev | up_due | xn_due;
+        // an injected particle beyond the upstream free-escape boundary (see refresh_thr): slow_post for the escape scalars of
+        // the crossing, slow_pre for the exit
+        feb_due = thr & (p.i_grid <= h.i_grid_feb) & p.inj & (p.x < h.feb_up);
+        ev = ev | up_due | xn_due | feb_due;
       }
       [[maybe_unused]] const bool unusual = (p.flags != 0) | (p.helix >= MCS_HELIX_CAP) | h.every_pass;
-      const bool post_pending = moved && (ev || ev_x || (p.flags & (F_NEARFEB | F_INJCHK)) != 0);
+      const bool post_pending = moved && (ev || ev_x || (p.flags & F_INJCHK) != 0);
       int end = -1;
       // What is due, from the state the move left (the expressions of move_and_detect).  A lane with nothing but
       // a plain zone crossing, a time cut, a fine/coarse switch or the cos_max refresh that follows one takes the
@@ -1988,7 +2002,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       // yet and comes from x_old <= 0 -- slow_pre's etf_ev; `inj` as slow_post / plain_crossing leave it)
       const bool etf_due = h.etf & ev_x & !(p.inj | (p.downstream & (p.x < 0))) & (p.x_old <= 0);
       bool full = (p.flags & ~F_CM) != 0 || p.helix >= MCS_HELIX_CAP || h.every_pass || etf_due || h.custom_epsB ||
-                  (ev && (h.odd_cfg || up_due || age_out));
+                  (ev && (h.odd_cfg || up_due || age_out || feb_due));
       TT_MARK(32);
       if (!full && ev_x) full = !plain_crossing(a, h, p, ev_pending);
       TT_MARK(33);
@@ -2033,7 +2047,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         PROF_LANES(24, moved && p.downstream && p.acctime >= p.t_ev);
         PROF_LANES(25, (p.flags & (F_RS | F_RM)) != 0);
         PROF_LANES(26, full && !unusual && !ev);
-        PROF_LANES(27, (p.flags & F_NEARFEB) != 0);
+        PROF_LANES(27, p.i_grid <= h.i_grid_feb);
         PROF_LANES(28, (p.flags & F_SAVE) != 0);
         PROF_LANES(29, !moved);
       }
@@ -2047,7 +2061,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           if (!(p.flags & F_B1)) break;
           pend = block1_step(a, h, p, phi_prev, end);
           if (end >= 0) break;
-          pend = pend || (p.flags & F_NEARFEB) != 0;
+          pend = pend || p.i_grid <= h.i_grid_feb;      // (as the reference: all_flux! in full after every move in the FEB zones)
           t_clock = p.t_step;
         }
         TT_MARK(17);

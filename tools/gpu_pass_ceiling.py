@@ -2,7 +2,7 @@
 the rare region in every pass) are carried ~6-9 r_g0 towards the shock in the 10^4 fine passes of the helix cap and never reach an
 edge, the shock or a PRP, so every lane runs common passes from load to cap -- no rare region after the first
 visit, no divergence, no tail (all histories have the same length).  What the kernel does then is the ceiling of the design.
-usage: python tools/gpu_pass_ceiling.py [N]"""
+usage: python tools/gpu_pass_ceiling.py [N [log10 p_lo  log10 p_hi [x / r_g0]]]"""
 import sys
 sys.path.insert(0, "tests")
 import numpy as np
@@ -16,7 +16,8 @@ LO, HI = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (-1.
 pop.ptot_pf[:] = mc * 10 ** rng.uniform(LO, HI, N)
 pop.pb_pf[:] = pop.ptot_pf * rng.uniform(-1, 1, N)
 pop.weight[:] = 1.0 / N
-pop.x_PT_cm[:] = -75.0 * prob.rg0
+X_RG = float(sys.argv[4]) if len(sys.argv) > 4 else -75.0          # (e.g. -8e6: zone 1, one of the upstream FEB zones)
+pop.x_PT_cm[:] = X_RG * prob.rg0
 pop.grid[:] = np.searchsorted(prob.x_grid_cm, pop.x_PT_cm, side="right") - 1
 pop.downstream[:] = 0; pop.inj[:] = 0
 pop.xn_per[:] = prob.params.xn_per_fine
@@ -37,5 +38,5 @@ for rep in range(2):
     ng, IC = prob.n_grid, mcs.capi.IC
     steps = int(I[ng + IC["STEPS_HELIX"]]) - (0 if rep == 0 else steps0)
     steps0 = int(I[ng + IC["STEPS_HELIX"]])
-    print(f"N = {N}, log10(p / m_p c) in [{LO}, {HI}]: {steps} steps ({steps / N:.1f} per particle, HELIX_CAP exits so far {int(I[ng + IC['HELIX_CAP']])}), kernel {hb.last_kernel()} {ms:.2f} ms -> "
+    print(f"N = {N}, x = {X_RG} r_g0, log10(p / m_p c) in [{LO}, {HI}]: {steps} steps ({steps / N:.1f} per particle, HELIX_CAP exits so far {int(I[ng + IC['HELIX_CAP']])}), kernel {hb.last_kernel()} {ms:.2f} ms -> "
           f"{steps / (ms * 1e-3):.3e} steps/s = {steps * 400 / (ms * 1e-3) / 78.6e12:.3f} of the fp64 VALU peak by the 400-flop weight", flush=True)
