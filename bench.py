@@ -12,7 +12,7 @@ shock, fp64, the 45 stock pcuts, scattering and DSA on -- i.e. init_pop (K3), th
 for every pcut the transport kernel (K1) + compaction/splitting (K2), then the
 merge of the tallies.  Weak scaling: every rank carries 10^6 particles of ONE global
 population of N x 10^6, dealt out like cards (rank r holds global particles r, r + N, ...; global RNG keys); per
-pcut an all-gather of n_saved and of the saved particles' global indices (8 B each; the particles themselves only in
+pcut an all-gather of n_saved and of the saved particles' global indices (4 B each; the particles themselves only in
 the late pcuts, when few are saved), one sum-all-reduce of the tallies per species (RCCL).  Synthetic data: the thermal
 injection of the reference's own initialiser.  `value` = total (helix + retro) steps
 of all ranks / max-over-ranks wall time of the K timed steps.
@@ -278,7 +278,7 @@ def main():
             "config": {"workload": workload_label(args),
                        "particles_per_gpu": args.particles, "particles_total": n_global, "species_tallies": args.species_tallies,
                        "steps_per_iteration": steps_total / args.steps,
-                       "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 8 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},
+                       "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 4 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_label(args), "launches": n_launch,
