@@ -2174,8 +2174,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       PROF_LANES(9, run & active); PROF_ADD(7, 1);
       if constexpr (LOSSY) {
         // slow_pre's radiative loss (particle_loop.jl:302-326 -> :578-592) and what hangs on the momentum, for a lane on which
-        // every other statement of slow_pre is a no-op: no flag set (so not near p_max, not to be saved, not in the FEB zone,
-        // zone loaded), nothing pending from the last move (the clock and position events stop a lane before this).  The
+        // every other statement of slow_pre is a no-op: no flag set (so not near p_max, not to be saved, zone loaded), nothing
+        // pending from the last move (the clock and the position thresholds -- the upstream FEB among them -- stop a lane before this).  The
         // momentum only decreases here, so F_NEARP / F_SAVE stay clear; the cone is refreshed with the xn_per of before this
         // pass's fine / coarse decision, as slow_pre does; t_clock is the time step of the previous move.
         if (run && !(rep == 0 && loss_done)) {
