@@ -254,7 +254,7 @@ def test_crafted_electrons_losses_and_prp_shortening():
     ob.destroy()
 
 
-@pytest.mark.parametrize("kind", ["protons", "electrons"])
+@pytest.mark.parametrize("kind", ["protons", "general", "electrons", "oblique"])
 def test_fuzzed_caller_populations_oracle_vs_twin(kind):
     """The random caller-provided populations of the GPU test test_fuzzed_caller_populations_vs_oracle (conftest.fuzz_population:
     every combination of downstream / inj, positions from beyond the upstream FEB to downstream of x_grid_stop, the PRP on either
