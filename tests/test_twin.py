@@ -258,11 +258,11 @@ def test_crafted_electrons_losses_and_prp_shortening():
 def test_fuzzed_caller_populations_oracle_vs_twin(kind):
     """The random caller-provided populations of the GPU test test_fuzzed_caller_populations_vs_oracle (conftest.fuzz_population:
     every combination of downstream / inj, positions from beyond the upstream FEB to downstream of x_grid_stop, the PRP on either
-    side, ages around age_max, every time-cut index), 40 particles, through the oracle and the twin: the oracle is right about
+    side, ages around age_max, every time-cut index), 120 particles, through the oracle and the twin: the oracle is right about
     the states the path itself never produces -- e.g. the `inj` update after the first move of a downstream-flagged particle
     loaded at x < 0 (particle_loop.jl:433-435), which the HIP path once missed."""
     from conftest import fuzz_population, fuzz_problem
-    N = 40
+    N = 120
     prob, aa = fuzz_problem(kind, N)
     ob = oracle_backend(prob, math="libm", nthreads=1)
     tw, *bases = _begin_species(prob, ob, 1, True)
