@@ -199,8 +199,7 @@ __shared__ unsigned int S_evcur[4];         // per-wave stack height
 #define F_ZONE    0x004   // i_grid != ig3: Code Block 3 has to reload the zone (particle_loop.jl:186-246)
 #define F_B1      0x008   // next pass is Code Block 1 (i_return == 1 after a PRP return, particle_loop.jl:167-177)
 #define F_NEARP   0x010   // ptot_pf > pmax_cutoff: the p_max exit needs its transform (particle_loop.jl:264)
-#define F_NEARFEB 0x020   // (fp32 kernel only) i_grid <= i_grid_feb: FEB exit test and all_flux's upstream special case every pass.  The fp64 kernel
-                          // does not set it since round 3: see `near_feb` in refresh_thr
+#define F_NEARFEB 0x020   // (not set since round 3: the upstream free-escape boundary is a position threshold, see `near_feb` in refresh_thr)
 #define F_SAVE    0x040   // downstream && ptot_pf > pcut: saved for the next pcut at the next Code Block 3
 #define F_CROSSED 0x080   // the last move changed i_grid (energy transfer test, particle_loop.jl:235)
 #define F_CHECK   0x100   // a time / fine-coarse event happened: re-run the exit tests and the xn decision
