@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
 
 // The common pass's version of move_and_detect: same move, the position events through the two thresholds.
 // Returns the events that are not position thresholds (odd configurations); ev_cross = some threshold reached.
-__device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross) {
+__device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross, const bool xn_is_threshold = true) {
   const int ig3 = p.ig3;
   const double gsf = p.z_gsf, bcos = p.z_bcos, ux = p.z_ux;
   p.x_old = p.x;
@@ -1113,8 +1113,9 @@ __device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, 
     const bool fwd = p.x > p.x_old;
     const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
     const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
-    const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
-    if ((!same_zone | ev_up | ev_xn) & !ev_cross) p.weight = __builtin_nan("");
+    const bool ev_xn = xn_is_threshold & ((p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse));      // (LOSSY: decided in line)
+    const bool ev_feb = (p.i_grid <= h.i_grid_feb) & p.inj & (p.x < h.feb_up);                          // (the upstream free-escape boundary)
+    if ((!same_zone | ev_up | ev_xn | ev_feb) & !ev_cross) p.weight = __builtin_nan("");
   }
 #endif
   bool ev = false;
@@ -2235,7 +2236,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           bool x1;
           // (the helix cap rides on the ev bit: the pass about to start would be number cap + 1; slow_post finds nothing
           // due for such a lane and slow_pre ends the particle, quirk Q5)
-          const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1) | ev_time | (p.helix >= MCS_HELIX_CAP);
+          const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1, !LOSSY) | ev_time | (p.helix >= MCS_HELIX_CAP);
           evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
           stopped = e1 | x1;
         }
