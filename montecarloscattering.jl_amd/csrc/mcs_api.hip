@@ -121,6 +121,9 @@ struct mcs_ctx {
   bool tail_merge = true;      // MCS_TAIL_MERGE=0: no consolidation of sparse waves (A/B measurements)
   int kernel_last = -1;        // mcs_last_kernel
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
+  bool k1_ws = true;           // MCS_K1_WS=0: the lane-owns-particle kernels (transport_body) also where the wave-specialised one applies
+  int ws_pop_max = 0;          // MCS_WS_POP=<n>: particles a block of the wave-specialised kernel holds at most (0: lanes + 160)
+  int ws_serve_min = 64;       // MCS_WS_SERVE=<n>: pending particles at which a wave serves them
   // consumers (K4): table staging, outputs, thermo scratch slab
   double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
   // launch
@@ -273,6 +276,9 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   } while (0)
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_K1_WS"); c->k1_ws = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_WS_POP"); if (e && std::atoi(e) >= 64 && std::atoi(e) <= 4096) c->ws_pop_max = std::atoi(e); }
+  { const char* e = std::getenv("MCS_WS_SERVE"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->ws_serve_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_F32_LOOP"); c->f32_loop = e && e[0] == '1'; }
@@ -698,15 +704,25 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool plain_etf = plain_but_etf && !plain;      // the ions of a run with energy transfer: PLAIN with that one flag at run time
   // the specialised kernel for electrons with radiative losses (transport_body<false, LOSSY>): the loss in line in the common pass
   const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
+  // the wave-specialised form of those two (mcs_transport_ws.inc): 512-thread blocks, one per CU
+  const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32 && budget == 0 && c->claim_max_first == 64 && c->blocks <= 0;
+  int k1_threads = threads;
+  if (ws) {
+    k1_threads = 512;
+    const long long want = (n + 511) / 512;
+    blocks = (int)(want < c->n_cu ? (want > 0 ? want : 1) : c->n_cu);
+    a.ws_pop_max = c->ws_pop_max > 0 ? c->ws_pop_max : 512 + 160;
+    a.ws_serve_min = c->ws_serve_min;
+  }
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
-  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)));
+  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
       if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : (lossy ? 2 : 0), blocks, 256, c->stream));
-      else HIPCHK(mcs_launch_transport(c->d_args, plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)), blocks, threads, c->stream));
+      else HIPCHK(mcs_launch_transport(c->d_args, ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))), blocks, k1_threads, c->stream));
       c->rep_dirty = true;
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -745,9 +761,14 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // the compaction half of new_pcut, queued behind the kernel: src[] for mcs_new_pcut / mcs_saved_export and an
   // independent count of the l_save flags next to the kernel's own n_saved counter, read back together
   HIPCHK(mcs_launch_compact(c->d_lsave, n, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src, c->stream));
-  HIPCHK(hipMemcpyAsync(c->h_back, c->d_counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_back, c->d_counters + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   const unsigned long long ns[2] = {c->h_back[0], c->h_back[1]};
+  if (ws && c->h_back[2] != 0) {
+    static char msg[160];
+    std::snprintf(msg, sizeof msg, "mcs_run_pcut: a bounded wait of the wave-specialised kernel ran out (the launch is incomplete; code 0x%llx)", (unsigned long long)c->h_back[2]);
+    return fail(msg);
+  }
   if (budget == 0) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -66,6 +66,8 @@ struct KArgs {
   double* strag_out;         // where this launch exports to (same layout; room for one entry per lane of the launch)
   unsigned long long* strag_count;   // entries written to strag_out (device counter, zeroed by the host)
   int budget_trips;          // 0: no export, every wave runs its particles to their end
+  int ws_pop_max;            // wave-specialised kernel (mcs_transport_ws.inc): particles a block holds at most (lanes + queued)
+  int ws_serve_min;          // ... and the number of pending particles at which a wave serves them (64)
   int claim_max;             // live particles a wave holds at most (64; less spreads a sparse queue over the waves of the chip:
                              // a pass costs a wave the same with 1 live lane as with 64, but every live lane's rare work stalls the others)
 };

@@ -1130,6 +1130,8 @@ __device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, 
 
 // Everything the last move triggered (the tail of Code Block 2 and Code Block 3's all_flux /
 // downstream_test / prob_return part, particle_loop.jl:352-358, 409-499).  Returns the end code or -1.
+// DIRECT (wave-specialised kernel): the crossing is tallied on the spot instead of being pushed as a record
+template <bool DIRECT = false>
 __device__ __forceinline__ int slow_post(CK* a, const Hot& h, Rng& rng, Pt& p, double phi_old) {
   const double aa = h.aa;
   const int ig3 = p.ig3;
@@ -1180,7 +1182,10 @@ __device__ __forceinline__ int slow_post(CK* a, const Hot& h, Rng& rng, Pt& p, d
       if (found < 0) { cnt(a, MCS_IC_ZONE_FAIL); return 3; }   // D6
       p.i_grid = found;
       load_zone_edges(p);
-      if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) push_record(p, ig3);
+      if (!(p.i_grid == p.i_grid_old && p.i_grid > h.i_grid_feb && h.n_xspec == 0)) {
+        if constexpr (DIRECT) flux_tally(a, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, ig3, p.inj);
+        else push_record(p, ig3);
+      }
     }
   }
   TTG_MARK(42);
@@ -1356,6 +1361,7 @@ __device__ __forceinline__ bool block1_step(CK* a, const Hot& h, Pt& p, double& 
 // the FEB zone).  What slow_post + slow_pre would do then is: inj update (particle_loop.jl:433-435),
 // the all_flux record (all_flux.jl:68-82, 130-137) and the zone reload of the next Code Block 3
 // (particle_loop.jl:186-204); every exit test is known to be false.  Returns false if it is not that case.
+template <bool DIRECT = false>
 __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsigned stack_height) {
   const int ne = h.n_grid + 2;
   const bool fwd = p.x > p.x_old;
@@ -1387,7 +1393,8 @@ __device__ __forceinline__ bool plain_crossing(CK* a, const Hot& h, Pt& p, unsig
     p.inj = p.inj | (p.downstream & (p.x < 0));
     p.i_grid_old = p.i_grid;
     p.i_grid = cand;
-    push_record(p, p.ig3, (int)stack_height);     // the first push site of a pass: the height is the register mirror
+    if constexpr (DIRECT) flux_tally(a, p.pb_pf, p.p_perp, p.ptot_pf, p.gam_pf, p.phi, p.weight, p.x, p.x_old, p.i_grid, p.i_grid_old, p.ig3, p.inj);
+    else push_record(p, p.ig3, (int)stack_height);     // the first push site of a pass: the height is the register mirror
     p.ig3 = cand;
     p.z_lo = c_lo; p.z_hi = c_hi; p.z_gsf = gsf_c; p.z_bcos = bcos_c; p.z_ux = ux_c; p.z_gef = gef_c;
   }
@@ -2283,6 +2290,7 @@ extern "C" int mcs_prof_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+#include "mcs_transport_ws.inc"
 #include "mcs_transport_f32.inc"
 
 extern "C" size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts) { (void)n_grid; (void)n_tcuts; return 0; }   // static LDS
@@ -2294,6 +2302,8 @@ extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blo
   if (kind == 1) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 2) hipLaunchKernelGGL(mcs_k_transport_lossy, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 6) hipLaunchKernelGGL(mcs_k_transport_plain_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 7) hipLaunchKernelGGL(mcs_k_transport_ws, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 8) hipLaunchKernelGGL(mcs_k_transport_ws_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);
   return hipGetLastError();
 }
