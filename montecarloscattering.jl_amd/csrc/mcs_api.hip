@@ -18,6 +18,7 @@ extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
+int mcs_transport_ws_threads(void);
 hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
@@ -121,7 +122,8 @@ struct mcs_ctx {
   bool tail_merge = true;      // MCS_TAIL_MERGE=0: no consolidation of sparse waves (A/B measurements)
   int kernel_last = -1;        // mcs_last_kernel
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
-  bool k1_ws = true;           // MCS_K1_WS=0: the lane-owns-particle kernels (transport_body) also where the wave-specialised one applies
+  bool k1_ws = false;          // MCS_K1_WS=1: the wave-specialised kernels (mcs_transport_ws.inc) where they apply -- measured at parity with
+                               // transport_body in the bulk of a launch and behind it in the tail (profiles/r04_ws_kernel_ab.txt): off by default
   int ws_pop_max = 0;          // MCS_WS_POP=<n>: particles a block of the wave-specialised kernel holds at most (0: lanes + 160)
   int ws_serve_min = 64;       // MCS_WS_SERVE=<n>: pending particles at which a wave serves them
   // consumers (K4): table staging, outputs, thermo scratch slab
@@ -276,7 +278,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   } while (0)
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
-  { const char* e = std::getenv("MCS_K1_WS"); c->k1_ws = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_K1_WS"); c->k1_ws = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_WS_POP"); if (e && std::atoi(e) >= 64 && std::atoi(e) <= 4096) c->ws_pop_max = std::atoi(e); }
   { const char* e = std::getenv("MCS_WS_SERVE"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->ws_serve_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
@@ -309,9 +311,9 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
     CRCHK(hipMemsetAsync(c->d_tally_rep, 0, nrep * sizeof(double), c->stream));
   }
   CRCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  c->own_T = c->own_I = true;      // (before the allocations: mcs_destroy on a failure below frees whichever exists)
   CRCHK(hipMalloc((void**)&c->d_T, (size_t)c->L.total * sizeof(double)));
   CRCHK(hipMalloc((void**)&c->d_I, (size_t)mcs_i64_total(p) * sizeof(unsigned long long)));
-  c->own_T = c->own_I = true;
   CRCHK(hipMemsetAsync(c->d_T, 0, (size_t)c->L.total * sizeof(double), c->stream));
   CRCHK(hipMemsetAsync(c->d_I, 0, (size_t)mcs_i64_total(p) * sizeof(unsigned long long), c->stream));
   CRCHK(hipEventCreate(&c->ev0));
@@ -604,6 +606,7 @@ int mcs_set_launch(mcs_ctx* c, int blocks, int threads) {
 int mcs_set_debug_finals(mcs_ctx* c, int on) { c->debug_finals = on != 0; return 0; }
 int mcs_set_tail_slicing(mcs_ctx* c, int budget_trips) {
   if (budget_trips < 0 || budget_trips > (1 << 24)) return fail("mcs_set_tail_slicing: budget out of range");
+  if (budget_trips > 0 && c->P.state_fp32) return fail("mcs_set_tail_slicing: the fp32-state kernels are not sliced (fp64 contexts only)");
   c->tail_budget = budget_trips;
   return 0;
 }
@@ -643,10 +646,16 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   if (n > 0) HIPCHK(hipMemsetAsync(c->d_lsave, 0, (size_t)n, c->stream));
   HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
   const int budget = (c->P.state_fp32 || n == 0) ? 0 : c->tail_budget;      // (the fp32 study kernel is not sliced)
-  if (budget > 0 && !c->d_strag[0]) {
-    // one entry per lane a launch can hold: 2 workgroups of 256 threads per CU
-    c->strag_cap = (long long)2 * c->n_cu * 256;
-    for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void**)&c->d_strag[b], (size_t)c->strag_cap * MCS_STRAG_WORDS * sizeof(double)));
+  if (budget > 0) {
+    // one entry per lane a launch can hold: 2 workgroups of 256 threads per CU, or the geometry of mcs_set_launch if that is larger
+    long long need_cap = (long long)2 * c->n_cu * 256;
+    if (c->blocks > 0 && (long long)c->blocks * c->threads > need_cap) need_cap = (long long)c->blocks * c->threads;
+    if (need_cap > c->strag_cap) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      for (int b = 0; b < 2; ++b) { if (c->d_strag[b]) (void)hipFree(c->d_strag[b]); c->d_strag[b] = nullptr; }
+      c->strag_cap = need_cap;
+      for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void**)&c->d_strag[b], (size_t)c->strag_cap * MCS_STRAG_WORDS * sizeof(double)));
+    }
   }
 
   KArgs& a = *c->h_args_pin;     // (every launch below is followed by a stream synchronisation before this is written again)
@@ -708,10 +717,10 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32 && budget == 0 && c->claim_max_first == 64 && c->blocks <= 0;
   int k1_threads = threads;
   if (ws) {
-    k1_threads = 512;
-    const long long want = (n + 511) / 512;
+    k1_threads = mcs_transport_ws_threads();
+    const long long want = (n + k1_threads - 1) / k1_threads;
     blocks = (int)(want < c->n_cu ? (want > 0 ? want : 1) : c->n_cu);
-    a.ws_pop_max = c->ws_pop_max > 0 ? c->ws_pop_max : 512 + 160;
+    a.ws_pop_max = c->ws_pop_max > 0 ? c->ws_pop_max : k1_threads + 160;
     a.ws_serve_min = c->ws_serve_min;
   }
   double ms_total = 0.0;

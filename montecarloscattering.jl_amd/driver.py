@@ -186,7 +186,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     if dev_t is not None:
         steps_seen = int(dev_t[1][i_h].item() + dev_t[1][i_r].item())
     else:
-        _, _i0 = backend.read_tallies_light() if hasattr(backend, "read_tallies_light") else backend.read_tallies()
+        # (the two counter words only: run_overlapped calls run() once per iteration)
+        _i0 = backend.read_counters() if hasattr(backend, "read_counters") else backend.read_tallies()[1]
         steps_seen = int(_i0[i_h] + _i0[i_r])
     iter_finals = []
     if smoothing is not None:
@@ -382,14 +383,18 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 itf.populate_eps_target(prob)        # src/main_loops.jl:76-81, top of the next iteration
                 backend.set_grid(prob)
                 backend.set_cuts(prob)
-        if tcut_print and P.do_tcuts and is_root:
+        if tcut_print and P.do_tcuts:
             # (after iter_finalize, as at src/main_loops.jl:363-389; G_f is the merged buffer of the last species, which holds the
-            # coupled arrays of every species -- they are per-ion slices of one array)
+            # coupled arrays of every species -- they are per-ion slices of one array).  The rewrite is applied to a COPY of the
+            # buffer -- the entries already handed out in per_species / on_species_end stay the raw sums -- and on every rank, so
+            # that all ranks return the same RunResult; only the root writes the device buffer.
             from . import iter_finalize as _itf
+            G_f = G_f.copy()
             wc, sc = L.view(G_f, "weight_coupled"), L.view(G_f, "spectra_coupled")
             _itf.tcut_print(wc, sc, len(prob.tcuts), P.num_psd_mom_bins)
-            backend.write_tally("weight_coupled", wc)
-            backend.write_tally("spectra_coupled", sc)
+            if is_root:
+                backend.write_tally("weight_coupled", wc)
+                backend.write_tally("spectra_coupled", sc)
         if on_iteration_end is not None:
             on_iteration_end(i_iter)
 
@@ -471,7 +476,7 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
     ng = P.n_grid
     total = []                                # the step counters are running totals of a context: where each one starts
     for be in backends:
-        _, i0 = be.read_tallies_light() if hasattr(be, "read_tallies_light") else be.read_tallies()
+        i0 = be.read_counters() if hasattr(be, "read_counters") else be.read_tallies()[1]
         total.append(int(i0[ng + IC["STEPS_HELIX"]] + i0[ng + IC["STEPS_RETRO"]]))
     with ThreadPoolExecutor(max_workers=K) as pool:
         futs = [pool.submit(one, i) for i in range(first_iter, first_iter + n_itrs)]

@@ -257,6 +257,12 @@ class HipBackend:
         self._chk(self.lib.mcs_read_tallies_part(self.h, first, tail.size, _dp(tail), i.ctypes.data_as(c_int64_p)))
         return f, i
 
+    def read_counters(self):
+        """The int64 tallies alone (num_crossings + event counters: ~1 KB), no fp64 word."""
+        i = np.zeros(self.layout.n_i64, dtype=np.int64)
+        self._chk(self.lib.mcs_read_tallies_part(self.h, 0, 0, None, i.ctypes.data_as(c_int64_p)))
+        return i
+
     def write_tallies(self, f, i):
         f = np.ascontiguousarray(f, dtype=np.float64)
         i = np.ascontiguousarray(i, dtype=np.int64)

@@ -296,8 +296,8 @@ def tcut_print(weight_coupled, spectra_coupled, n_tcuts: int, num_psd_mom_bins: 
                 weight_coupled[ion, tc] = 1.0e-99
             sp = spectra_coupled[ion, tc]
             tot = 0.0
-            for v in sp:                     # Julia's sum over a 201-element slice is a plain left-to-right loop below
-                tot += v                     # its pairwise block size (1024): the same order here
+            for v in sp:                     # left to right.  Julia's `sum` below its pairwise block size (1024) is an @simd loop that
+                tot += v                     # LLVM may reassociate: agreement with the reference's normaliser to ~1 ulp, not order identity
             if tot > 1.0e-99:
                 sp /= tot
             head = sp[:num_psd_mom_bins + 1]

@@ -473,6 +473,43 @@ def test_specialised_and_general_kernel_agree(monkeypatch, case):
     assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
 
 
+@pytest.mark.parametrize("case,N", [("plain", 4000), ("plain", 70000), ("plain_etf", 4000), ("plain", 300)])
+def test_wave_specialised_kernel_is_bit_identical(monkeypatch, case, N):
+    """MCS_K1_WS=1 runs the common configuration through mcs_k_transport_ws (csrc/mcs_transport_ws.inc): particles are 29-word
+    records that move between lanes and waves through LDS rings, the rare code is served 64 lanes wide by whichever wave finds 64
+    particles pending.  State and RNG stream position travel with the particle, so every particle, saved array and integer tally
+    must equal those of the lane-owns-particle kernel (last_kernel 1 / 6) -- which the other tests pin to the oracle -- and the
+    binned tallies differ by the order of their adds only.  Sizes: several blocks with a full population (70 000: 137 blocks), a
+    few sparse blocks (4000), less than one block (300)."""
+    kw = {} if case == "plain" else dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)],
+                                         energy_transfer_frac=0.1, radiation_losses=True)
+    prob = make_problem(N, **kw)
+    out = []
+    for ws in ("1", "0"):
+        monkeypatch.setenv("MCS_K1_WS", ws)
+        hb = hip_backend(prob)
+        start_species(hb, prob)
+        fin = []
+        for ip in range(1, 10):
+            n = hb.pop_size()
+            ns = hb.run_pcut(ip, 0)
+            fin.append((hb.finals(), hb.get_saved()))
+            if ns == 0: break
+            hb.new_pcut(max(n // ns, 1))
+        out.append((fin, hb.read_tallies()))
+        assert hb.last_kernel() == {("1", "plain"): 7, ("1", "plain_etf"): 8, ("0", "plain"): 1, ("0", "plain_etf"): 6}[(ws, case)]
+        hb.destroy()
+    (fa, (Ta, Ia)), (fb, (Tb, Ib)) = out
+    assert len(fa) == len(fb)
+    for (xa, (sa, la)), (xb, (sb, lb)) in zip(fa, fb):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), k
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, "saved arrays, wave-specialised vs lane-owns-particle kernel")
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
+
+
 @pytest.mark.parametrize("case", ["crafted", "thermal_mixed"])
 def test_lossy_kernel_agrees_with_general_and_oracle(monkeypatch, case):
     """Electrons with radiative losses run mcs_k_transport_lossy: the loss of every pass (particle_loop.jl:302-326) and the
@@ -539,8 +576,8 @@ def test_lossy_kernel_agrees_with_general_and_oracle(monkeypatch, case):
         assert_tallies_close(L, Ta, Tb, TALLY_RTOL)
 
 
-@pytest.mark.parametrize("kind", ["protons", "general", "electrons", "oblique"])
-def test_fuzzed_caller_populations_vs_oracle(kind):
+@pytest.mark.parametrize("kind", ["protons", "general", "electrons", "oblique", "protons_ws"])
+def test_fuzzed_caller_populations_vs_oracle(kind, monkeypatch):
     """mcs_pop_upload takes any population, not only the ones the path produces: 8192 random particles (conftest.fuzz_population --
     every combination of downstream / inj, positions from beyond the upstream FEB to downstream of x_grid_stop and within 1e-7
     r_g of the shock, six decades of momentum, the PRP on either side, ages around age_max, every time-cut index) through three
@@ -551,7 +588,10 @@ def test_fuzzed_caller_populations_vs_oracle(kind):
     downstream-flagged particle loaded at x < 0: DESIGN.md section 3.)"""
     from conftest import fuzz_population, fuzz_problem
     N = 8192
-    prob, aa = fuzz_problem(kind, N)
+    if kind == "protons_ws":       # the same population through the wave-specialised kernel (csrc/mcs_transport_ws.inc)
+        monkeypatch.setenv("MCS_K1_WS", "1")
+        kind = "protons+ws"
+    prob, aa = fuzz_problem(kind.split("+")[0], N)
     pop = fuzz_population(prob, N, 1, aa)
     assert int(((pop.downstream == 1) & (pop.inj == 0) & (pop.x_PT_cm < 0)).sum()) > 100
     sp = prob.cfg.species[0]
@@ -572,7 +612,7 @@ def test_fuzzed_caller_populations_vs_oracle(kind):
         return out, be.read_tallies()
     hb, ob = hip_backend(prob), oracle_backend(prob, nthreads=16)
     (fa, (Ta, Ia)), (fb, (Tb, Ib)) = run(hb), run(ob)
-    assert hb.last_kernel() == {"protons": 1, "general": 0, "electrons": 2, "oblique": 0}[kind]
+    assert hb.last_kernel() == {"protons": 1, "general": 0, "electrons": 2, "oblique": 0, "protons+ws": 7}[kind]
     reasons = np.zeros(5, dtype=np.int64)
     assert len(fa) == len(fb)
     for ip, ((xa, (sa, la)), (xb, (sb, lb))) in enumerate(zip(fa, fb), 2):
