@@ -296,6 +296,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample, n_sample_1t=args.cpu_sample_1t)
         if overlap_leg:
             out["overlapped_iterations"] = overlapped_leg(mcs, hip_backend, prob, be, local, args)
+        if args.mixed and world == 1:
+            # the photon leg of config[4] ("inverse-Compton/synch photon tallies"): ion_finalize's photon_calcs for the electron
+            # species on the histograms the last iteration left on the device (K4 dN/dp, K5 synchrotron, K6 get_dNdp_2D + IC).
+            # Reported beside the headline: it is O(bins) work per species, outside the particle loop the metric counts.
+            i_e = len(prob.cfg.species)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            fin = mcs.consumers.ion_finalize(prob, be, i_e)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            ph_s = mcs.consumers.photon_synch(prob, be, fin, i_e)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            ph_i = mcs.consumers.photon_ic(prob, be, i_e)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            out["photon_leg"] = {"ion_finalize_ms": (t1 - t0) * 1e3, "synch_ms": (t2 - t1) * 1e3, "dndp_2d_plus_ic_ms": (t3 - t2) * 1e3,
+                                 "synch_zones_lit": int((ph_s.emis_erg_s > 1e-99).any(axis=1).sum()),
+                                 "ic_zones_lit": int((ph_i.emis_erg > 1e-99).any(axis=1).sum()),
+                                 "note": "electron species of the last iteration; wall time incl. table upload and the read-back of the spectra"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

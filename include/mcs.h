@@ -323,6 +323,21 @@ int mcs_thermo_calcs(mcs_ctx* ctx, const mcs_consumer_in* in, double* P_par, dou
 int mcs_photon_synch(mcs_ctx* ctx, const double* dNdp_pf, const double* mom_edge_cgs, double mc, int n_photon, double emin_mev,
                      double bins_per_dec, double* energy_erg, double* emis);
 
+/* get_dNdp_2D (src/particle_counter.jl:343-627, called at src/ion_finalize.jl:50-59) on the resident psd / therm_sf / num_crossings:
+ * d2N/dp dcos of every zone, normalised to the zone population, rebinned by cell centres into the frame that moves with
+ * (gam_x, beta_x) against the shock frame -- the ISM frame for (gam0, beta0), the only frame the function returns (m = 2, :538).
+ * Uses mom_edge_cgs, cos_center, pt_center, zone_pop, rest_energy, n0, therm_from_hist of `in`.  The array stays on the device for
+ * mcs_photon_ic; d2N: host [n_grid][ntht+2][nmom+2] (momentum fastest), floor 1e-99, may be NULL. */
+int mcs_dndp_2d(mcs_ctx* ctx, const mcs_consumer_in* in, double gam_x, double beta_x, double* d2N);
+/* The inverse-Compton fold of src/inverse_compton.jl:36-311 (photon_IC -> IC_emission_FCJ: Jones 1968, eq. 9) over the array the last
+ * mcs_dndp_2d left on the device, per grid zone.  j_max: last angle bin inside the jet cone (inverse_compton.jl:215); alpha_in /
+ * n_in [n_nu <= 60]: energies (in m_e c^2) and number densities of the incoming photon field (photon_field!, :313-383: host table);
+ * photon energies E_k = emin_mev * 10^(k / bins_per_dec); beam_area = 4 pi d_lum^2 jet_sph_frac.  Outputs (host): energy_erg[n_photon]
+ * (may be NULL), emis[n_grid][n_photon] = observed energy flux per d(ln E) at Earth in erg / (s cm^2), floor 1e-99 (:285-308).
+ * Dead code in the reference, followed as specification (include/mcs_ic.h lists where it cannot run as written). */
+int mcs_photon_ic(mcs_ctx* ctx, const double* mom_edge_cgs, double mc_e, int j_max, int n_nu, const double* alpha_in, const double* n_in, int n_photon,
+                  double emin_mev, double bins_per_dec, double beam_area, double* energy_erg, double* emis);
+
 /* ---- test / measurement hooks ------------------------------------------- */
 /* evaluate device math/RNG primitives (bit-parity tests): fn ids in mcs_fn */
 enum mcs_fn { MCS_FN_SIN = 0, MCS_FN_COS, MCS_FN_ASIN, MCS_FN_ACOS, MCS_FN_ATAN2, MCS_FN_LOG10,

@@ -184,8 +184,7 @@ def photon_synch(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: flo
     src/synch_emission.jl over the plasma-frame dN/dp (frame 2 of get_dNdp_cr; the thermal part is empty, quirk C4), on the
     device (K5), then photon_synch's conversion to fluxes at Earth (src/photon_synch.jl:74-108) with the luminosity distance
     of photon_calcs.jl:40.  The photon stack is dead code in the reference: followed as
-    specification.  Inverse Compton needs d2N/dp dcos in the explosion frame, which get_dNdp_2D never produces (C4): not built;
-    pion decay concerns nuclei."""
+    specification.  Inverse Compton: `photon_ic` below; pion decay concerns nuclei and is not built."""
     P = prob.params
     sp = prob.cfg.species[i_ion - 1]
     if sp.aa >= 1:
@@ -199,3 +198,92 @@ def photon_synch(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: flo
     eflux_MeV = np.where(flux_erg > 1.0e-99, flux_erg / MEV_ERG, 1.0e-99)
     pflux = np.where(eflux_MeV <= 1.0e-99, 1.0e-99, eflux_MeV / E_MeV[None, :])
     return PhotonSynch(E_MeV, emis, eflux_MeV, pflux)
+
+
+# ---- inverse Compton (src/photon_calcs.jl:116-138 -> src/inverse_compton.jl) ---------------------------------------------------
+PHOTON_IC_E_MIN_MEV = 1.0e-2          # photon_calcs.jl:18
+PHOTON_E_MAX_MEV = 1.0e12             # photon_calcs.jl:11
+T_CMB0_K = 2.725                      # constants.jl:12
+WIEN_B_NU = 5.879e10                  # Hz / K (inverse_compton.jl:167)
+H_PLANCK = 6.62607015e-27             # erg s
+ME = 9.1093837015e-28                 # g
+
+
+def photon_field_cmb(redshift: float = 0.0):
+    """`photon_field!` (src/inverse_compton.jl:313-383): the CMB at the source's redshift as 60 logarithmic frequency bins between
+    nu_peak / 30 and 20 nu_peak -> (photon energy / m_e c^2, photons per cm^3) per bin."""
+    T = T_CMB0_K * (1 + redshift)
+    nu_peak = WIEN_B_NU * T
+    n_nu = 60
+    log_nu_min = math.log10(nu_peak / 30)
+    dlog = (math.log10(nu_peak * 20) - log_nu_min) / n_nu
+    con_f1 = 8 * math.pi * H_PLANCK / C ** 3
+    con_f2 = H_PLANCK / (KB * T)
+    alpha, dens = np.zeros(n_nu), np.zeros(n_nu)
+    for j in range(1, n_nu + 1):
+        log_nu1 = log_nu_min + (j - 1) * dlog
+        nu1, nu2 = 10.0 ** log_nu1, 10.0 ** (log_nu1 + dlog)
+        nu_avg = math.sqrt(nu1 * nu2)
+        exp_fac = math.exp(min(con_f2 * nu_avg, 200.0))
+        u = (nu2 - nu1) * con_f1 * nu_avg ** 3 / (exp_fac - 1)
+        e = H_PLANCK * nu_avg
+        alpha[j - 1] = e / (ME * C * C)
+        dens[j - 1] = u / e
+    return alpha, dens
+
+
+def ic_cone_last_bin(cos_edge: np.ndarray, jet_sph_frac: float, num_psd_tht_bins: int) -> int:
+    """`findfirst(>(2 jet_sph_frac - 1), cos_bounds)` (src/inverse_compton.jl:215): the last angle bin whose electrons can send
+    photons to Earth; every bin when nothing exceeds the bound (a full sphere) or the hit lies past the last bin (mcs_ic.h, I2)."""
+    hit = np.nonzero(cos_edge > 2 * jet_sph_frac - 1)[0]
+    j = int(hit[0]) if len(hit) else num_psd_tht_bins
+    return min(j, num_psd_tht_bins)
+
+
+@dataclasses.dataclass
+class PhotonIC:
+    """What `photon_IC` computes per grid zone (src/inverse_compton.jl:36-188) -- it writes it to photon_IC_grid.dat."""
+    energy_MeV: np.ndarray         # [n_photon]
+    emis_erg: np.ndarray           # [n_grid][n_photon]  energy flux per d(ln E) at Earth, erg / (cm^2 s), floor 1e-99
+    energy_flux_MeV: np.ndarray    # [n_grid][n_photon]  the same in MeV / (cm^2 s), floor 1e-99
+    photon_flux: np.ndarray        # [n_grid][n_photon]  photons / (cm^2 s) per d(ln E), floor 1e-99
+    ic_photon_sum: np.ndarray      # [n_grid][n_photon]  1e-99 + emis / E (the array get_summed_emission reads, :100-104)
+    d2N_ef: object = None          # [n_grid][ntht+2][nmom+2] get_dNdp_2D's array, if it was downloaded
+
+
+def photon_ic(prob, backend, i_ion: int, jet_dist_kpc: float = 1.0e6, redshift: float = 0.0, jet_sph_frac=None,
+              download_d2n: bool = False, therm_from_hist: bool = True) -> PhotonIC:
+    """The inverse-Compton branch of `photon_calcs` (src/photon_calcs.jl:116-138) for the electron species: `get_dNdp_2D`
+    (src/particle_counter.jl:343-627 as called at src/ion_finalize.jl:50-59: the electrons' d2N/dp dcos in the ISM frame) and
+    `photon_IC` -> `IC_emission_FCJ` on the CMB of `photon_field!` (src/inverse_compton.jl), both on the device (K6) on the
+    histograms K1 left there; then photon_IC's conversions (:93-133).  Dead code in the reference, followed as specification
+    (include/mcs_ic.h: I1-I3)."""
+    P = prob.params
+    sp = prob.cfg.species[i_ion - 1]
+    if sp.aa >= 1:
+        raise ValueError("photon_ic: inverse-Compton emission is computed for the electron species (aa < 1)")
+    if jet_sph_frac is None:
+        jet_sph_frac = jet_sphere_fraction(prob.cfg)
+    if not 0 < jet_sph_frac <= 1:
+        raise ValueError("photon_ic: the jet must cover a fraction 0 < f <= 1 of the sphere (JETFR)")
+    tabs = consumer_tables(prob, i_ion, therm_from_hist)
+    if _takes_download(backend):
+        d2n = backend.dndp_2d(tabs, P.gam0, P.beta0, download=download_d2n)
+    else:
+        d2n = backend.dndp_2d(tabs, P.gam0, P.beta0)
+    n_photon = int(math.log10(PHOTON_E_MAX_MEV / PHOTON_IC_E_MIN_MEV) * PHOTON_BINS_PER_DEC)          # photon_calcs.jl:50
+    alpha_in, n_in = photon_field_cmb(redshift)
+    j_max = ic_cone_last_bin(tabs.cos_edge, jet_sph_frac, P.num_psd_tht_bins)
+    dist_lum = jet_dist_kpc * (1 + redshift) * KPC_CM
+    beam_area = 4 * math.pi * dist_lum ** 2 * jet_sph_frac
+    E_erg, emis = backend.photon_ic(tabs.mom_edge_cgs, tabs.mc, j_max, alpha_in, n_in, n_photon, PHOTON_IC_E_MIN_MEV, PHOTON_BINS_PER_DEC, beam_area)
+    E_MeV = E_erg / MEV_ERG
+    eflux_MeV = np.where(emis > 1.0e-99, emis / MEV_ERG, 1.0e-99)
+    pflux = np.where(eflux_MeV <= 1.0e-99, 1.0e-99, eflux_MeV / E_MeV[None, :])
+    ic_sum = 1.0e-99 + np.where(emis > 1.0e-99, emis / E_erg[None, :], 0.0)
+    return PhotonIC(E_MeV, emis, eflux_MeV, pflux, ic_sum, d2n)
+
+
+def _takes_download(backend) -> bool:
+    import inspect
+    return "download" in inspect.signature(backend.dndp_2d).parameters

@@ -6,6 +6,7 @@
 // on ONE HIP stream; mcs_run_pcut is synchronous only for the 8-byte n_saved.
 // There is no CPU code path in this library.
 #include "mcs_device.h"
+#include "../../include/mcs_ic.h"
 
 #include <cmath>
 #include <cstdio>
@@ -39,6 +40,10 @@ hipError_t mcs_launch_copy(double* dst, const double* src, long long n, hipStrea
 hipError_t mcs_launch_eval(int fn, long long n, const double* a, const double* b, double* out, hipStream_t st);
 hipError_t mcs_launch_dndp_cr(const mcs_params* P, const double* psd, const double* gam_sf, const double* ux, const double* tabs,
                               double rest_energy, double n0, double gam0, double* out_dndp, unsigned long long* diag, hipStream_t st);
+hipError_t mcs_launch_dndp_2d(const mcs_params* P, const double* psd, const double* therm_sf, const unsigned long long* num_crossings, const double* tabs,
+                              double rest_energy, double n0, int therm_from_hist, double gam_x, double beta_x, double* scratch, double* ef, hipStream_t st);
+hipError_t mcs_launch_photon_ic(const double* ef, const double* p_edge, const double* field, int n_grid, int NM, int NT, int j_max, int n_nu, int n_photon,
+                                double log_min_rm, double bins_per_dec, double mc_e, double beam_area, double* out, hipStream_t st);
 hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
                                    double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st);
 hipError_t mcs_launch_thermo(const mcs_params* P, const double* psd, const double* therm_pf, const unsigned long long* num_crossings,
@@ -128,6 +133,7 @@ struct mcs_ctx {
   int ws_serve_min = 64;       // MCS_WS_SERVE=<n>: pending particles at which a wave serves them
   // consumers (K4): table staging, outputs, thermo scratch slab
   double* d_ctab = nullptr; double* d_cout = nullptr; double* d_cscratch = nullptr; unsigned long long* d_cdiag = nullptr;
+  double* d_c2d = nullptr; bool have_c2d = false;    // d2N/dp dcos of the last mcs_dndp_2d ([n_grid][ntht+2][nmom+2]), the input of mcs_photon_ic
   // launch
   int blocks = 0, threads = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -332,7 +338,7 @@ int mcs_destroy(mcs_ctx* c) {
   pop_free(c->cur); pop_free(c->sav); pop_free(c->spare);
   void* ptrs[] = {c->d_tab, c->d_cuts, c->d_lsave, c->f_reason, c->f_helix, c->f_retro, c->f_ptot, c->f_x,
                   c->d_bcounts, c->d_boffs, c->d_src, c->d_counters, c->d_stage, c->d_args, c->d_tally_rep,
-                  c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag, c->d_strag[0], c->d_strag[1]};
+                  c->d_ctab, c->d_cout, c->d_cscratch, c->d_cdiag, c->d_strag[0], c->d_strag[1], c->d_c2d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_T && c->d_T) (void)hipFree(c->d_T);
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
@@ -998,6 +1004,58 @@ int mcs_photon_synch(mcs_ctx* c, const double* dNdp_pf, const double* mom_edge_c
   HIPCHK(hipMemcpyAsync(emis, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (energy_erg) for (int j = 0; j < n_photon; ++j) energy_erg[j] = std::pow(10.0, log_emin + j * (1.0 / bins_per_dec));
+  return 0;
+}
+
+// get_dNdp_2D (src/particle_counter.jl:343-627) on the resident psd / therm_sf / num_crossings: the d2N/dp dcos of every zone in
+// the frame that moves with (gam_x, beta_x) against the shock frame (the ISM frame: gam0, beta0).  The result stays on the device
+// for mcs_photon_ic; d2N (host, [n_grid][ntht+2][nmom+2], momentum fastest) may be null.
+int mcs_dndp_2d(mcs_ctx* c, const mcs_consumer_in* in, double gam_x, double beta_x, double* d2N) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (consumers_ready(c, in, "mcs_dndp_2d")) return 1;
+  if (fold_replicas(c)) return 1;
+  if (!in->mom_edge_cgs || !in->cos_center || !in->pt_center || !in->zone_pop) return fail("mcs_dndp_2d: null table");
+  if (!(gam_x >= 1) || !(beta_x >= 0 && beta_x < 1)) return fail("mcs_dndp_2d: bad frame");
+  const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
+  const size_t slab = (size_t)NM * NT * ng;
+  if (!c->d_cscratch) HIPCHK(hipMalloc((void**)&c->d_cscratch, sizeof(double) * slab));
+  if (!c->d_c2d) HIPCHK(hipMalloc((void**)&c->d_c2d, sizeof(double) * slab));
+  std::vector<double> h((size_t)(2 * NM + NT + ng), 0.0);
+  memcpy(h.data(), in->mom_edge_cgs, sizeof(double) * NM);
+  memcpy(h.data() + NM, in->cos_center, sizeof(double) * (NT - 1));
+  memcpy(h.data() + NM + NT, in->pt_center, sizeof(double) * (NM - 1));
+  memcpy(h.data() + 2 * NM + NT, in->zone_pop, sizeof(double) * ng);
+  HIPCHK(hipMemcpyAsync(c->d_ctab, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(mcs_launch_dndp_2d(&c->P, c->d_T + c->L.psd, c->d_T + c->L.therm_sf, c->d_I + MCS_I_NUM_CROSSINGS, c->d_ctab, in->rest_energy, in->n0,
+                            in->therm_from_hist, gam_x, beta_x, c->d_cscratch, c->d_c2d, c->stream));
+  if (d2N) HIPCHK(hipMemcpyAsync(d2N, c->d_c2d, sizeof(double) * slab, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->have_c2d = true;
+  return 0;
+}
+
+// The inverse-Compton fold (include/mcs_ic.h) over the d2N/dp dcos the last mcs_dndp_2d left on the device.
+int mcs_photon_ic(mcs_ctx* c, const double* mom_edge_cgs, double mc_e, int j_max, int n_nu, const double* alpha_in, const double* n_in, int n_photon,
+                  double emin_mev, double bins_per_dec, double beam_area, double* energy_erg, double* emis) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (!c || !mom_edge_cgs || !alpha_in || !n_in || !emis) return fail("mcs_photon_ic: null argument");
+  if (!c->have_c2d) return fail("mcs_photon_ic: no mcs_dndp_2d result on the device");
+  const int NM = c->P.num_psd_mom_bins + 2, NT = c->P.num_psd_tht_bins + 2, ng = c->P.n_grid;
+  if (NM > 208) return fail("mcs_photon_ic: too many momentum bins");
+  if (n_photon < 1 || n_photon > 4096 || n_nu < 1 || n_nu > MCS_IC_NNU || j_max < 0 || j_max > NT - 2 || !(emin_mev > 0) || !(bins_per_dec > 0) ||
+      !(mc_e > 0) || !(beam_area > 0))
+    return fail("mcs_photon_ic: bad arguments");
+  const size_t n_in_w = (size_t)NM + 2 * (size_t)n_nu, n_out = (size_t)ng * n_photon;
+  if (ensure_stage(c, (long long)(n_in_w + n_out) + 4)) return 1;
+  double* d_in = c->d_stage; double* d_out = c->d_stage + n_in_w;
+  HIPCHK(hipMemcpyAsync(d_in, mom_edge_cgs, sizeof(double) * NM, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_in + NM, alpha_in, sizeof(double) * n_nu, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_in + NM + n_nu, n_in, sizeof(double) * n_nu, hipMemcpyHostToDevice, c->stream));
+  const double log_min_rm = std::log10(emin_mev * MCS_MEV_ERG_ / (MCS_ME * MCS_C * MCS_C));
+  HIPCHK(mcs_launch_photon_ic(c->d_c2d, d_in, d_in + NM, ng, NM, NT, j_max, n_nu, n_photon, log_min_rm, bins_per_dec, mc_e, beam_area, d_out, c->stream));
+  HIPCHK(hipMemcpyAsync(emis, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (energy_erg) for (int k = 0; k < n_photon; ++k) energy_erg[k] = mcs_ic_alpha_out(log_min_rm, bins_per_dec, k) * (MCS_ME * MCS_C * MCS_C);
   return 0;
 }
 

@@ -15,6 +15,7 @@
 #include "mcs_device.h"
 #include "../../include/mcs_math.h"
 #include "../../include/mcs_synch.h"
+#include "../../include/mcs_ic.h"
 
 #pragma clang fp contract(off)
 
@@ -334,6 +335,98 @@ __global__ void __launch_bounds__(256) mcs_k_thermo(ConsArgs a) {
   if (threadIdx.x == 0) { a.out_par[i - 1] = pp0 + sp; a.out_perp[i - 1] = pq0 + sq; a.out_edens[i - 1] = ed0 + se; }
 }
 
+
+
+// ---- K6: get_dNdp_2D (src/particle_counter.jl:343-627, called at src/ion_finalize.jl:50-59) and the inverse-Compton fold
+// (src/inverse_compton.jl:36-311, called at src/photon_calcs.jl:116-138) -- SURVEY.md 8(f-4) --------------------------------------
+// mcs_k_dndp_2d: one workgroup per grid zone.  d2N/dp dcos of the zone in the shock frame = the thermal crossings (binned on the
+// fly by K1 into therm_sf: A9) + the psd cells above 1e-66, divided by dp, normalised to the zone population (:376-519); then the
+// centre-point rebin of every cell into the frame moving with (gam_x, beta_x) against the shock frame -- the ISM frame, m = 2 of
+// :531-598 (the plasma-frame array of the same loop is never read and is not built).  `sf`: the zone's slab of a scratch buffer,
+// `ef`: of the output; both [ntht+2][nmom+2], momentum fastest (the psd's own layout).
+__global__ void __launch_bounds__(256) mcs_k_dndp_2d(ConsArgs a, const double* __restrict__ therm_sf, double gam_x, double beta_x, double* __restrict__ ef_out) {
+  __shared__ double s_red[4];
+  __shared__ double s_dp[KC_MAXB];
+  const mcs_params& P = a.P;
+  const int nm = P.num_psd_mom_bins, nt = P.num_psd_tht_bins;
+  const int NM = nm + 2, NT = nt + 2;
+  const int i = blockIdx.x + 1;
+  const long long slab = (long long)NM * NT;
+  const double* psd = a.psd + slab * (i - 1);
+  const double* ths = therm_sf + slab * (i - 1);
+  double* sf = a.scratch + slab * (i - 1);
+  double* ef = ef_out + slab * (i - 1);
+  const unsigned long long ncross = a.num_crossings[i - 1];
+  const double E0 = a.rest_energy;
+  for (int k = threadIdx.x; k <= nm; k += blockDim.x) s_dp[k] = a.mom_edge[k + 1] - a.mom_edge[k];      // Delta p (:376-380; C1: cgs edges)
+  __syncthreads();
+  // thermal crossings (:430-451), CR cells (:466-472), dN -> dN/dp (:475-480)
+  double part = 0.0;
+  for (long long q = threadIdx.x; q < slab; q += blockDim.x) {
+    const int k = (int)(q % NM), j = (int)(q / NM);
+    double v = 1.0e-99;
+    if (ncross != 0ull && a.therm_from_hist) v += ths[q];
+    if (k <= nm && j <= nt) { const double w = psd[q]; if (w > 1.0e-66) v += w; }
+    if (k <= nm && v > 1.0e-66) v /= s_dp[k];
+    sf[q] = v;
+    ef[q] = 1.0e-99;
+    if (v > 1.0e-66) part += v;
+  }
+  // density of the array and the rescaling to the zone population (:487-519)
+  double dens = c_block_sum(part, s_red);
+  if (ncross == 0ull && dens > 0) dens += a.n0;
+  const double norm = dens > 0 ? a.zone_pop[i - 1] / dens : 0.0;
+  __threadfence(); __syncthreads();
+  // the centre-point rebin (:548-598)
+  const int ncell = (nm + 1) * (nt + 1);
+  for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
+    const int k = q % (nm + 1), j = q / (nm + 1);
+    double v = sf[k + NM * j];
+    v = (v > 1.0e-99 && norm > 0) ? v * norm : 1.0e-99;
+    if (v <= 1.0e-66) continue;
+    const double w = v * s_dp[k];
+    const double cs = a.cos_center[j], pt = a.pt_center[k];
+    const double px = pt * cs;
+    const double pc = pt * MCS_C;
+    const double et = __builtin_sqrt(pc * pc + E0 * E0);                  // hypot(ptot c, E0)
+    const double pxX = gam_x * (px - beta_x * et / MCS_C);
+    const double ptX = __builtin_sqrt(pt * pt - px * px + pxX * pxX);
+    const int kX = c_bin_mom(P, ptX), jX = c_bin_ang(P, pxX, ptX);
+    c_gadd(&ef[kX + NM * jX], w / s_dp[kX]);
+  }
+}
+
+// mcs_k_photon_ic: one workgroup per grid zone, one thread per outgoing photon energy; every thread walks the electron momentum
+// bins and the incoming photon bins in the reference's order (include/mcs_ic.h), so a spectrum is the same sum in the same order
+// on the CPU twin.  The electrons of a momentum bin inside the jet cone are counted once per zone (one thread per bin, angle bins in
+// order: photon_IC's conversion to particle counts, inverse_compton.jl:54-61, and the sums of :235-238).
+__global__ void __launch_bounds__(256) mcs_k_photon_ic(const double* __restrict__ ef /*[n_grid][NT][NM]*/, const double* __restrict__ p_edge /*[NM]*/,
+                                                      const double* __restrict__ field /*alpha_in[n_nu] | n_in[n_nu]*/, int NM, int NT, int j_max, int n_nu,
+                                                      int n_photon, double log_min_rm, double bins_per_dec, double mc_e, double beam_area,
+                                                      double* __restrict__ out /*[n_grid][n_photon]*/) {
+  __shared__ double s_x[KC_MAXB], s_g[KC_MAXB], s_a[MCS_IC_NNU], s_n[MCS_IC_NNU];
+  const int zone = blockIdx.x + 1, nm = NM - 2;
+  const double* d2 = ef + (long long)(zone - 1) * NM * NT;
+  for (int i = threadIdx.x; i <= nm; i += blockDim.x) {
+    const double dp = p_edge[i + 1] - p_edge[i];
+    double mx = 0.0, sum = 0.0;
+    for (int j = 0; j <= j_max; ++j) {
+      const double v = d2[i + NM * j];
+      const double c = v <= 1.0e-99 ? 1.0e-99 : v * dp;
+      mx = c > mx ? c : mx;
+      sum += c;
+    }
+    s_x[i] = mx <= 1.0e-99 ? 0.0 : sum;
+    s_g[i] = mcs_ic_gamma(p_edge[i], p_edge[i + 1], mc_e);
+  }
+  for (int j = threadIdx.x; j < n_nu; j += blockDim.x) { s_a[j] = field[j]; s_n[j] = field[n_nu + j]; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_photon; k += blockDim.x) {
+    const double ao = mcs_ic_alpha_out(log_min_rm, bins_per_dec, k);
+    out[(long long)(zone - 1) * n_photon + k] = mcs_ic_emis(mcs_ic_fold_one(s_x, s_g, nm + 1, s_a, s_n, n_nu, ao), ao, beam_area);
+  }
+}
+
 }  // namespace
 
 // Host-callable launchers (pointers are device pointers; tables were uploaded by the caller)
@@ -390,5 +483,24 @@ __global__ void __launch_bounds__(256) mcs_k_photon_synch(const double* __restri
 extern "C" hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
                                               double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st) {
   hipLaunchKernelGGL(mcs_k_photon_synch, dim3((unsigned)n_grid), dim3(256), 0, st, dndp_pf, p_edge, btot, NM, n_photon, log_emin_erg, bins_per_dec, mc, out);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mcs_launch_dndp_2d(const mcs_params* P, const double* psd, const double* therm_sf, const unsigned long long* num_crossings,
+                                         const double* tabs /*mom_edge[NM] | cos_center[NT] | pt_center[NM] | zone_pop[ng]*/, double rest_energy, double n0,
+                                         int therm_from_hist, double gam_x, double beta_x, double* scratch, double* ef, hipStream_t st) {
+  ConsArgs a{};
+  a.P = *P;
+  const int NM = P->num_psd_mom_bins + 2, NT = P->num_psd_tht_bins + 2;
+  a.psd = psd; a.num_crossings = num_crossings;
+  a.mom_edge = tabs; a.cos_center = tabs + NM; a.pt_center = tabs + NM + NT; a.zone_pop = tabs + 2 * NM + NT;
+  a.rest_energy = rest_energy; a.n0 = n0; a.therm_from_hist = therm_from_hist; a.scratch = scratch;
+  hipLaunchKernelGGL(mcs_k_dndp_2d, dim3(P->n_grid), dim3(256), 0, st, a, therm_sf, gam_x, beta_x, ef);
+  return hipGetLastError();
+}
+extern "C" hipError_t mcs_launch_photon_ic(const double* ef, const double* p_edge, const double* field, int n_grid, int NM, int NT, int j_max, int n_nu,
+                                           int n_photon, double log_min_rm, double bins_per_dec, double mc_e, double beam_area, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(mcs_k_photon_ic, dim3((unsigned)n_grid), dim3(256), 0, st, ef, p_edge, field, NM, NT, j_max, n_nu, n_photon, log_min_rm, bins_per_dec,
+                     mc_e, beam_area, out);
   return hipGetLastError();
 }

@@ -300,6 +300,25 @@ class HipBackend:
         self._chk(self.lib.mcs_photon_synch(self.h, _dp(d), _dp(pe), float(mc), int(n_photon), float(emin_mev), float(bins_per_dec), _dp(E), _dp(out)))
         return E, out
 
+    def dndp_2d(self, tabs, gam_x, beta_x, download=True):
+        """K6: get_dNdp_2D on the resident histograms -> d2N/dp dcos [n_grid][ntht+2][nmom+2] in the frame (gam_x, beta_x); the array
+        stays on the device for photon_ic (download=False: nothing crosses PCIe)."""
+        P = self.P
+        out = np.zeros((P.n_grid, P.num_psd_tht_bins + 2, P.num_psd_mom_bins + 2)) if download else None
+        s = tabs.as_struct()
+        self._chk(self.lib.mcs_dndp_2d(self.h, ct.byref(s), float(gam_x), float(beta_x), _dp(out) if download else None))
+        return out
+
+    def photon_ic(self, mom_edge_cgs, mc_e, j_max, alpha_in, n_in, n_photon, emin_mev, bins_per_dec, beam_area):
+        """K6: inverse-Compton energy flux per d(ln E) at Earth [erg/(s cm^2)] per zone from the d2N/dp dcos of the last dndp_2d."""
+        pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        ai = np.ascontiguousarray(alpha_in, dtype=np.float64); ni = np.ascontiguousarray(n_in, dtype=np.float64)
+        assert pe.shape == (self.P.num_psd_mom_bins + 2,) and ai.shape == ni.shape
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.mcs_photon_ic(self.h, _dp(pe), float(mc_e), int(j_max), int(len(ai)), _dp(ai), _dp(ni), int(n_photon), float(emin_mev),
+                                         float(bins_per_dec), float(beam_area), _dp(E), _dp(out)))
+        return E, out
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.mcs_last_kernel_ms(self.h))
 

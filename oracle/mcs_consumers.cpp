@@ -31,6 +31,7 @@
 //    bin absorbs the remainder so the cell weight is conserved.)
 #include "../include/mcs.h"
 #include "../include/mcs_synch.h"
+#include "../include/mcs_ic.h"
 
 #include <cmath>
 #include <cstdint>
@@ -333,5 +334,78 @@ int orc_photon_synch(const mcs_params* Pp, const double* dNdp_pf, const double* 
   return 0;
 }
 double orc_synch_F(double x) { return mcs_synch_F(x); }
+
+// get_dNdp_2D (src/particle_counter.jl:343-627), CPU twin of mcs_dndp_2d: d2N/dp dcos per zone in the shock frame from the thermal
+// crossings (therm_sf histogram: A9) and the psd, normalised to the zone population, rebinned by cell centres into the frame moving
+// with (gam_x, beta_x) -- m = 2 of :531-598 for (gam0, beta0).  d2N: [n_grid][ntht+2][nmom+2], momentum fastest.
+int orc_dndp_2d(const mcs_params* Pp, const double* T, const int64_t* I, const mcs_consumer_in* in, double gam_x, double beta_x, double* d2N) {
+  const mcs_params& P = *Pp;
+  mcs_layout L; mcs_tally_layout(Pp, &L);
+  const int nm = P.num_psd_mom_bins, nt = P.num_psd_tht_bins, ng = P.n_grid;
+  const int NM = nm + 2, NT = nt + 2;
+  const double E0 = in->rest_energy;
+  std::vector<double> sf(NM * (size_t)NT), dp(NM, 0.0);
+  for (int k = 0; k <= nm; ++k) dp[k] = in->mom_edge_cgs[k + 1] - in->mom_edge_cgs[k];                 // :376-380 (C1)
+  for (int i = 1; i <= ng; ++i) {
+    const double* psd = T + L.psd + L.psd_stride_zone * (int64_t)(i - 1);
+    const double* ths = T + L.therm_sf + L.psd_stride_zone * (int64_t)(i - 1);
+    double* ef = d2N + (size_t)NM * NT * (i - 1);
+    const int64_t ncross = I[MCS_I_NUM_CROSSINGS + (i - 1)];
+    for (size_t q = 0; q < sf.size(); ++q) { sf[q] = 1.0e-99; ef[q] = 1.0e-99; }                         // :361-363
+    if (ncross != 0 && in->therm_from_hist) for (size_t q = 0; q < sf.size(); ++q) sf[q] += ths[q];      // :430-451 via A9
+    for (int j = 0; j <= nt; ++j) for (int k = 0; k <= nm; ++k) { const double w = psd[k + NM * j]; if (w > 1.0e-66) sf[k + NM * j] += w; }   // :466-472
+    for (int j = 0; j < NT; ++j) for (int k = 0; k <= nm; ++k) if (sf[k + NM * j] > 1.0e-66) sf[k + NM * j] /= dp[k];                        // :475-480
+    double dens = 0.0;                                                                                    // :487-492
+    for (size_t q = 0; q < sf.size(); ++q) if (sf[q] > 1.0e-66) dens += sf[q];
+    if (ncross == 0 && dens > 0) dens += in->n0;                                                          // :505-507
+    const double norm = dens > 0 ? in->zone_pop[i - 1] / dens : 0.0;                                      // :510-514
+    for (size_t q = 0; q < sf.size(); ++q) sf[q] = (sf[q] > 1.0e-99 && norm > 0) ? sf[q] * norm : 1.0e-99;   // :517-523
+    for (int k = 0; k <= nm; ++k)                                                                          // :562-596
+      for (int j = 0; j <= nt; ++j) {
+        const double v = sf[k + NM * j];
+        if (v <= 1.0e-66) continue;
+        const double w = v * dp[k];
+        const double cs = in->cos_center[j], pt = in->pt_center[k];
+        const double px = pt * cs;
+        const double pc = pt * MCS_C;
+        const double et = MC::sqrt(pc * pc + E0 * E0);
+        const double pxX = gam_x * (px - beta_x * et / MCS_C);
+        const double ptX = MC::sqrt(pt * pt - px * px + pxX * pxX);
+        const int kX = bin_mom(P, ptX), jX = bin_ang(P, pxX, ptX);
+        ef[kX + NM * jX] += w / dp[kX];
+      }
+  }
+  return 0;
+}
+
+// The inverse-Compton fold (src/inverse_compton.jl:36-311), CPU twin of mcs_photon_ic: the same header (include/mcs_ic.h), glibc math.
+int orc_photon_ic(const mcs_params* Pp, const double* d2N /*[n_grid][ntht+2][nmom+2]*/, const double* mom_edge_cgs, double mc_e, int j_max, int n_nu,
+                  const double* alpha_in, const double* n_in, int n_photon, double emin_mev, double bins_per_dec, double beam_area,
+                  double* energy_erg, double* emis) {
+  const int NM = Pp->num_psd_mom_bins + 2, NT = Pp->num_psd_tht_bins + 2, ng = Pp->n_grid, nm = NM - 2;
+  const double log_min_rm = std::log10(emin_mev * MCS_IC_MEV_ERG / (MCS_ME * MCS_C * MCS_C));
+  std::vector<double> xnum(nm + 1), gam(nm + 1);
+  for (int zone = 1; zone <= ng; ++zone) {
+    const double* d2 = d2N + (size_t)(zone - 1) * NM * NT;
+    for (int i = 0; i <= nm; ++i) {
+      const double dp = mom_edge_cgs[i + 1] - mom_edge_cgs[i];
+      double mx = 0.0, sum = 0.0;
+      for (int j = 0; j <= j_max; ++j) {
+        const double v = d2[i + NM * j];
+        const double c = v <= 1.0e-99 ? 1.0e-99 : v * dp;                  // photon_IC, :54-61
+        mx = c > mx ? c : mx;
+        sum += c;
+      }
+      xnum[i] = mx <= 1.0e-99 ? 0.0 : sum;                                 // :235-238
+      gam[i] = mcs_ic_gamma(mom_edge_cgs[i], mom_edge_cgs[i + 1], mc_e);
+    }
+    for (int k = 0; k < n_photon; ++k) {
+      const double ao = mcs_ic_alpha_out(log_min_rm, bins_per_dec, k);
+      if (zone == 1 && energy_erg) energy_erg[k] = ao * (MCS_ME * MCS_C * MCS_C);
+      emis[(size_t)(zone - 1) * n_photon + k] = mcs_ic_emis(mcs_ic_fold_one(xnum.data(), gam.data(), nm + 1, alpha_in, n_in, n_nu, ao), ao, beam_area);
+    }
+  }
+  return 0;
+}
 
 }  // extern "C"

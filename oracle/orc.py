@@ -73,6 +73,8 @@ def load(math: str = "det", capi=None):
         sig["orc_dndp_cr"] = (i32, [par_p, dp, cin_p, dp, dp, dp, i64p])
         sig["orc_thermo_calcs"] = (i32, [par_p, dp, i64p, cin_p, dp, dp, dp, dp, dp])
         sig["orc_photon_synch"] = (i32, [par_p, dp, dp, dp, dbl, i32, dbl, dbl, dp, dp])
+        sig["orc_dndp_2d"] = (i32, [par_p, dp, i64p, cin_p, dbl, dbl, dp])
+        sig["orc_photon_ic"] = (i32, [par_p, dp, dp, dbl, i32, i32, dp, dp, i32, dbl, dbl, dbl, dp, dp])
         sig["orc_synch_F"] = (dbl, [dbl])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -280,6 +282,24 @@ class OracleBackend:
         self._chk(self.lib.orc_dndp_cr(ct.byref(P), _dp(f), ct.byref(s), _dp(gsf), _dp(ux), _dp(out),
                                        diag.ctypes.data_as(ct.POINTER(ct.c_int64))))
         return out, diag
+
+    def dndp_2d(self, tabs, gam_x, beta_x, tallies=None):
+        """get_dNdp_2D (CPU twin of mcs_dndp_2d) -> [n_grid][ntht+2][nmom+2]; kept for photon_ic."""
+        f, i = self.read_tallies() if tallies is None else tallies
+        P = self.P
+        out = np.zeros((P.n_grid, P.num_psd_tht_bins + 2, P.num_psd_mom_bins + 2))
+        s = tabs.as_struct()
+        self._chk(self.lib.orc_dndp_2d(ct.byref(P), _dp(f), i.ctypes.data_as(ct.POINTER(ct.c_int64)), ct.byref(s), float(gam_x), float(beta_x), _dp(out)))
+        self._d2n = out
+        return out
+
+    def photon_ic(self, mom_edge_cgs, mc_e, j_max, alpha_in, n_in, n_photon, emin_mev, bins_per_dec, beam_area):
+        pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        ai = np.ascontiguousarray(alpha_in, dtype=np.float64); ni = np.ascontiguousarray(n_in, dtype=np.float64)
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.orc_photon_ic(ct.byref(self.P), _dp(self._d2n), _dp(pe), float(mc_e), int(j_max), int(len(ai)), _dp(ai), _dp(ni),
+                                         int(n_photon), float(emin_mev), float(bins_per_dec), float(beam_area), _dp(E), _dp(out)))
+        return E, out
 
     def thermo_calcs(self, tabs, tallies=None):
         f, i = self.read_tallies() if tallies is None else tallies
