@@ -98,6 +98,8 @@ struct mcs_ctx {
   int claim_max_first = 64;    // MCS_CLAIM_MAX=<n> (environment): live particles per wave in the FIRST launch of a pcut (measurements of tau(L))
   double* d_strag[2] = {nullptr, nullptr}; long long strag_cap = 0;
   int f32_blocks_per_cu = 3;   // MCS_F32_BLOCKS=<n>: resident workgroups per CU the organised fp32 kernel is launched for (its occupancy)
+  bool f32_exact = false;      // MCS_F32_EXACT=1: the plain loop with the exact fp32 primitives (include/mcs_math_f32.h): the kernel the CPU restatement
+                               // oracle/mcs_oracle_f32.inc reproduces bit for bit (tests)
   bool f32_loop = false;       // MCS_F32_LOOP=1: the fp32-state variant as a plain per-lane loop (the reference semantics of that variant; tests)
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
   int refill_min = 12;         // MCS_REFILL_MIN=<n> (environment) overrides: A/B measurements
@@ -290,6 +292,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_F32_LOOP"); c->f32_loop = e && e[0] == '1'; }
+  { const char* e = std::getenv("MCS_F32_EXACT"); c->f32_exact = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_F32_BLOCKS"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 8) c->f32_blocks_per_cu = std::atoi(e); }
   { const char* e = std::getenv("MCS_TAIL_BUDGET"); if (e && std::atoi(e) >= 0) c->tail_budget = std::atoi(e); }
   { const char* e = std::getenv("MCS_CLAIM_MAX"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->claim_max_first = std::atoi(e); }
@@ -698,7 +701,7 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // two 256-thread blocks are resident per CU (78 KB of LDS each); the fp32-state kernel (27 KB, 119 VGPRs) fits four
   // (resident workgroups per CU: 2 for the fp64 kernel -- 78 KB of LDS each --, 3 for the organised fp32 kernel -- 168 VGPRs, 51 KB --,
   // 4 for its plain-loop form)
-  const long long full = (long long)c->n_cu * (c->P.state_fp32 ? (c->f32_loop ? 4 : c->f32_blocks_per_cu) : 2);
+  const long long full = (long long)c->n_cu * (c->P.state_fp32 ? ((c->f32_loop || c->f32_exact) ? 4 : c->f32_blocks_per_cu) : 2);
   if (blocks <= 0) {
     // persistent lanes: fill the chip, never launch more lanes than particles
     const long long want = (n + threads - 1) / threads;
@@ -731,12 +734,12 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   }
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
-  c->kernel_last = c->P.state_fp32 ? (c->f32_loop ? 4 : (lossy ? 5 : 3)) : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))));
+  c->kernel_last = c->P.state_fp32 ? (c->f32_exact ? 9 : (c->f32_loop ? 4 : (lossy ? 5 : 3))) : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
-      if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_loop ? 1 : (lossy ? 2 : 0), blocks, 256, c->stream));
+      if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_exact ? 3 : (c->f32_loop ? 1 : (lossy ? 2 : 0)), blocks, 256, c->stream));
       else HIPCHK(mcs_launch_transport(c->d_args, ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))), blocks, k1_threads, c->stream));
       c->rep_dirty = true;
     }

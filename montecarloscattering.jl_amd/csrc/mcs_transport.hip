@@ -39,6 +39,7 @@
 #include "mcs_device.h"
 #define MCS_DEVICE_FAST_SQRT 1
 #include "../../include/mcs_math.h"
+#include "../../include/mcs_math_f32.h"
 
 #pragma clang fp contract(off)
 

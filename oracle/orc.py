@@ -47,6 +47,7 @@ def load(math: str = "det", capi=None):
         "orc_begin_species": (i32, [vp, i32, i32, dbl, dbl, dbl, dbl, dbl]),
         "orc_set_fluxes": (i32, [vp, dp, dp, dp]),
         "orc_run_pcut": (i32, [vp, i32, i64, i64, i64, i64p, soa_p, soa_p, u8p, i64p, i32]),
+        "orc_run_pcut_f32": (i32, [vp, i32, i64, i64, i64, i64p, soa_p, soa_p, u8p, i64p]),
         "orc_set_retro_cap": (i32, [vp, i64]),
         "orc_finals": (i32, [vp, i64, i32p, i32p, i32p, dp, dp]),
         "orc_read_tallies": (i32, [vp, dp, i64p]),
@@ -179,6 +180,11 @@ class OracleBackend:
         self.l_save = np.zeros(n, dtype=np.uint8)
         ns = ct.c_int64(0)
         si, so = self.pop.soa(), self.saved.soa()
+        if getattr(self, "f32_exact", False):
+            # the fp32-state variant in its exact form (oracle/mcs_oracle_f32.inc; twin of MCS_F32_EXACT=1 on the device)
+            self._chk(self.lib.orc_run_pcut_f32(self.h, i_pcut, n, i_prt_offset, i_prt_stride, gp, ct.byref(si), ct.byref(so),
+                                                self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), ct.byref(ns)))
+            return int(ns.value)
         self._chk(self.lib.orc_run_pcut(self.h, i_pcut, n, i_prt_offset, i_prt_stride, gp, ct.byref(si), ct.byref(so),
                                         self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), ct.byref(ns), self.nthreads))
         return int(ns.value)
