@@ -701,7 +701,7 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // two 256-thread blocks are resident per CU (78 KB of LDS each); the fp32-state kernel (27 KB, 119 VGPRs) fits four
   // (resident workgroups per CU: 2 for the fp64 kernel -- 78 KB of LDS each --, 3 for the organised fp32 kernel -- 168 VGPRs, 51 KB --,
   // 4 for its plain-loop form)
-  const long long full = (long long)c->n_cu * (c->P.state_fp32 ? ((c->f32_loop || c->f32_exact) ? 4 : c->f32_blocks_per_cu) : 2);
+  const long long full = (long long)c->n_cu * (c->P.state_fp32 ? ((c->f32_loop || c->f32_exact) ? 3 : c->f32_blocks_per_cu) : 2);
   if (blocks <= 0) {
     // persistent lanes: fill the chip, never launch more lanes than particles
     const long long want = (n + threads - 1) / threads;
@@ -722,6 +722,8 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   const bool plain_etf = plain_but_etf && !plain;      // the ions of a run with energy transfer: PLAIN with that one flag at run time
   // the specialised kernel for electrons with radiative losses (transport_body<false, LOSSY>): the loss in line in the common pass
   const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
+  // sliced launches (suspend / resume, fewer than 64 particles per wave) run the general kernel's SLICED form
+  const bool sliced = !c->P.state_fp32 && (budget > 0 || c->claim_max_first < 64);
   // the wave-specialised form of those two (mcs_transport_ws.inc): 512-thread blocks, one per CU
   const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32 && budget == 0 && c->claim_max_first == 64 && c->blocks <= 0;
   int k1_threads = threads;
@@ -734,13 +736,13 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   }
   double ms_total = 0.0;
   c->tail_rounds_last = 0;
-  c->kernel_last = c->P.state_fp32 ? (c->f32_exact ? 9 : (c->f32_loop ? 4 : (lossy ? 5 : 3))) : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))));
+  c->kernel_last = c->P.state_fp32 ? (c->f32_exact ? 9 : (c->f32_loop ? 4 : (lossy ? 5 : 3))) : (sliced ? 10 : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)))));
   for (int round = 0;; ++round) {
     HIPCHK(hipMemcpyAsync(c->d_args, c->h_args_pin, sizeof(KArgs), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n > 0) {
       if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_args, c->f32_exact ? 3 : (c->f32_loop ? 1 : (lossy ? 2 : 0)), blocks, 256, c->stream));
-      else HIPCHK(mcs_launch_transport(c->d_args, ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0))), blocks, k1_threads, c->stream));
+      else HIPCHK(mcs_launch_transport(c->d_args, sliced ? 10 : (ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)))), blocks, k1_threads, c->stream));
       c->rep_dirty = true;
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));

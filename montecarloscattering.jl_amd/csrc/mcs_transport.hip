@@ -1618,7 +1618,11 @@ __device__ __forceinline__ void block_flush(CK* a) {
 // statements of slow_pre are no-ops (no flag set, nothing pending); a lane that has just run slow_pre in the rare region has
 // had this pass's loss there and skips the block once.  Same statements in the same order on the same values.
 // PLAIN_ETF: the PLAIN conditions with the ion -> electron energy transfer left as a run-time flag (the ions of a multi-species run)
-template <bool PLAIN, bool LOSSY = false, bool PLAIN_ETF = false>
+// SLICED: the launch may resume lane states an earlier launch exported, hold fewer than 64 particles per wave and export its live
+// particles a budget of trips after the queue ran dry (KArgs "sliced launches"; mcs_set_tail_slicing).  Measured not to pay
+// (DESIGN.md "Sliced tail"), so it is a kernel of its own (mcs_k_transport_sliced, the general form): the shipping kernels carry
+// neither its code nor its registers (round 3: +20 B/lane of scratch in mcs_k_transport_plain).
+template <bool PLAIN, bool LOSSY = false, bool PLAIN_ETF = false, bool SLICED = false>
 __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
@@ -1692,10 +1696,11 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const unsigned lane = __lane_id();
   // the launch's queue: first the resume list (lane states a previous launch exported), then the fresh particles
   // fresh_lo .. n-1 of the population (see KArgs: sliced launches)
-  const unsigned long long n_resume = (unsigned long long)a->n_resume;
-  const unsigned long long n = n_resume + (unsigned long long)(a->n - a->fresh_lo);
-  const unsigned budget = (unsigned)__builtin_amdgcn_readfirstlane(a->budget_trips);
-  const int claim_max = __builtin_amdgcn_readfirstlane(a->claim_max);
+  const unsigned long long n_resume = SLICED ? (unsigned long long)a->n_resume : 0ull;
+  const long long fresh_lo = SLICED ? a->fresh_lo : 0ll;
+  const unsigned long long n = n_resume + (unsigned long long)(a->n - fresh_lo);
+  const unsigned budget = SLICED ? (unsigned)__builtin_amdgcn_readfirstlane(a->budget_trips) : 0u;
+  const int claim_max = SLICED ? __builtin_amdgcn_readfirstlane(a->claim_max) : 64;
   unsigned mtick_ex = 0;            // mtick when this wave found the queue exhausted
 
   const unsigned wv = threadIdx.x >> 6;
@@ -1805,7 +1810,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           const int rank = (int)below(idle);
           const unsigned long long idx = base + (unsigned long long)rank;
           if (rank < nidle && idx >= n_resume && idx < n) {
-            k = a->fresh_lo + (long long)(idx - n_resume);
+            k = fresh_lo + (long long)(idx - n_resume);
             load_particle(a, h, k, p, rng);
             act = -1; evw = 0; rb = 0u - 256u;
             // wait for the loads HERE: the common pass then carries no vmcnt wait (which would also wait for
@@ -1816,7 +1821,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         // the head of the queue: particles an earlier launch exported.  Their lane states come in through the wave's record
         // stack, used as a mailbox exactly as in the tail consolidation (pending records are tallied first); up to
         // MCS_MB_SLOTS at a time.  (Through LDS because 36 global loads per lane in this loop cost ~100 spilled registers.)
-        if (!exhausted && __builtin_amdgcn_readfirstlane(base < n_resume ? 1 : 0)) {
+        if (SLICED && !exhausted && __builtin_amdgcn_readfirstlane(base < n_resume ? 1 : 0)) {
           drain_events(a, wv, lane, true); ev_pending = 0u;
           const unsigned long long left = n_resume - base;
           const unsigned cnt_r = (unsigned)(left < (unsigned long long)nidle ? left : (unsigned long long)nidle);
@@ -1855,7 +1860,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;
       };
       // (a sliced launch whose budget is spent exports below: the pair is closed first, a donation already made is taken and exported too)
-      const bool closing = budget != 0u && exhausted && mtick - mtick_ex >= budget;
+      const bool closing = SLICED && budget != 0u && exhausted && mtick - mtick_ex >= budget;
       if (mrole != 0 && exhausted) {
         unsigned mpartner;
         const unsigned mpair = pair_of(mpartner);
@@ -2280,6 +2285,9 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain_etf(const KArgs* __restrict__ ka) {
   transport_body<true, false, true>(ka);
 }
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_sliced(const KArgs* __restrict__ ka) {
+  transport_body<false, false, false, true>(ka);
+}
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
@@ -2303,6 +2311,7 @@ extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blo
   if (kind == 1) hipLaunchKernelGGL(mcs_k_transport_plain, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 2) hipLaunchKernelGGL(mcs_k_transport_lossy, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 6) hipLaunchKernelGGL(mcs_k_transport_plain_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 10) hipLaunchKernelGGL(mcs_k_transport_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 7) hipLaunchKernelGGL(mcs_k_transport_ws, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 8) hipLaunchKernelGGL(mcs_k_transport_ws_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);

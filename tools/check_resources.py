@@ -15,13 +15,21 @@ DEFAULT = os.path.join(ROOT, "montecarloscattering.jl_amd", "csrc", "mcs_transpo
 
 # kernel -> (max VGPRs, max VGPR spills, max scratch bytes/lane, required occupancy [waves/SIMD], max LDS bytes/block)
 LIMITS = {
-    "mcs_k_transport_plain": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
-    "mcs_k_transport": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
-    "mcs_k_transport_lossy": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
-    "mcs_k_transport_plain_etf": dict(vgprs=256, vgpr_spill=56, scratch=96, occupancy=2, lds=81920),
-    "mcs_k_transport_f32": dict(vgprs=168, vgpr_spill=64, scratch=512, occupancy=3, lds=54613),
-    "mcs_k_transport_f32_lossy": dict(vgprs=168, vgpr_spill=64, scratch=512, occupancy=3, lds=54613),
-    "mcs_k_transport_f32_loop": dict(vgprs=128, vgpr_spill=0, scratch=256, occupancy=4, lds=40960),
+    # round 4: suspend / resume is a kernel of its own (mcs_k_transport_sliced), the shipping kernels are back at <= 76 B/lane
+    "mcs_k_transport_plain": dict(vgprs=256, vgpr_spill=56, scratch=76, occupancy=2, lds=81920),
+    "mcs_k_transport": dict(vgprs=256, vgpr_spill=56, scratch=76, occupancy=2, lds=81920),
+    "mcs_k_transport_lossy": dict(vgprs=256, vgpr_spill=56, scratch=76, occupancy=2, lds=81920),
+    "mcs_k_transport_plain_etf": dict(vgprs=256, vgpr_spill=56, scratch=76, occupancy=2, lds=81920),
+    "mcs_k_transport_sliced": dict(vgprs=256, vgpr_spill=64, scratch=112, occupancy=2, lds=81920),
+    # the wave-specialised kernels (512-thread blocks, one per CU: up to 128 KB of LDS with the particle pool)
+    "mcs_k_transport_ws": dict(vgprs=256, vgpr_spill=24, scratch=76, occupancy=2, lds=131072),
+    "mcs_k_transport_ws_etf": dict(vgprs=256, vgpr_spill=24, scratch=76, occupancy=2, lds=131072),
+    # round 4: the retro walk is inlined in the fp32 kernels -- the 192-208 B/lane of rounds 2-3 were the frame of that one call
+    # (the 34-word lane state and the RNG stream passed by reference), not spills
+    "mcs_k_transport_f32": dict(vgprs=168, vgpr_spill=32, scratch=96, occupancy=3, lds=54613),
+    "mcs_k_transport_f32_lossy": dict(vgprs=168, vgpr_spill=32, scratch=96, occupancy=3, lds=54613),
+    "mcs_k_transport_f32_loop": dict(vgprs=168, vgpr_spill=0, scratch=0, occupancy=3, lds=40960),
+    "mcs_k_transport_f32_loop_exact": dict(vgprs=168, vgpr_spill=0, scratch=16, occupancy=3, lds=40960),
 }
 
 
