@@ -292,6 +292,12 @@ def main():
                                "gather_splits": sum(1 for s in timed if s.split == "gather"),
                                "local_splits": sum(1 for s in timed if s.split == "local"),
                                "note": "largest local population / mean, per pcut (1.0 = perfectly balanced)"}
+        if "MCS_BENCH_ONE_DEVICE" in os.environ:
+            # rehearsal of the N > 1 shape on one card: what the device holds with every rank's buffers resident
+            free_b, total_b = torch.cuda.mem_get_info()
+            out["rehearsal"] = {"ranks_on_one_device": world, "backend": backend, "device_mem_used_gb_at_end": (total_b - free_b) / 1e9,
+                                "torch_peak_alloc_gb_rank0": torch.cuda.max_memory_allocated() / 1e9,
+                                "note": "all ranks share ONE GPU: rates say nothing about scaling; host-side cost and footprint of the multi-rank path only"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample, n_sample_1t=args.cpu_sample_1t)
         if overlap_leg:

@@ -289,8 +289,10 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     # every rank splits its own saved particles; the index column alone goes round
                     g_loc = backend.saved_gidx()                                  # ascending, counts[rank] entries
                     cap = max(max(counts), 1)
-                    # (padded with the largest int64: every row of the gathered table stays sorted, so ONE batched searchsorted
-                    # counts, for each of my saved particles, the saved particles of every rank below it)
+                    # (padded with the largest integer: every row of the gathered table stays sorted; for each of my saved particles a
+                    # searchsorted per peer row counts that rank's saved particles below it.  One row at a time, accumulated in place:
+                    # the working set is O(n) -- round 3 searched all rows at once through an expanded [W, n] key matrix and an int64
+                    # [W, n] result, 0.5 + 0.8 GB per rank and pcut at config[3]'s 1.25e7 particles per GPU)
                     # (the column travels as int32 while every index fits: half the bytes on the wire and in the search -- 4 B per saved
                     # particle per peer, 32 MB per rank and pcut at 10^6 particles per GPU on 8 GPUs)
                     idt = torch.int32 if n_prev_global < 2 ** 31 - 1 else torch.int64
@@ -298,7 +300,9 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     pad = torch.full((cap,), torch.iinfo(idt).max, dtype=idt, device=g_loc.device)
                     pad[:g_key.numel()] = g_key
                     g_all = comm.all_gather_rows(pad)                             # [W, cap]
-                    pos = torch.searchsorted(g_all, g_key.unsqueeze(0).expand(g_all.shape[0], -1).contiguous()).sum(dim=0)
+                    pos = torch.zeros(g_key.numel(), dtype=torch.int64, device=g_loc.device)
+                    for w in range(g_all.shape[0]):
+                        pos += torch.searchsorted(g_all[w], g_key)
                     gidx = (pos[:, None] * i_mult + torch.arange(i_mult, dtype=torch.int64, device=g_loc.device)[None, :]).reshape(-1).contiguous()
                     backend.new_pcut(i_mult)
                     n_local = counts[comm.rank] * i_mult

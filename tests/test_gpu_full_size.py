@@ -164,6 +164,15 @@ def test_config2_population_properties_every_pcut_1e7():
     print(f"1e7 protons: {reached} pcuts reached, {n_done} exits")
 
 
+def test_config3_per_gpu_size_properties_5e7():
+    """BASELINE config[3] (1e8 particles over 2 / 4 / 8 GPUs) at its LARGEST per-GPU size, 5e7 particles on one GPU: the same
+    per-pcut properties (every particle ends once, counters equal exits, splits are i_mult copies in order, weight conserved,
+    the first 4096 particles equal the oracle's bit for bit) with 10 GB of population buffers resident.  The multi-GPU run
+    itself cannot be tested on a one-GPU box; what a rank of it computes is this."""
+    reached, n_done = _property_run(50_000_000)
+    print(f"5e7 protons: {reached} pcuts reached, {n_done} exits")
+
+
 def test_config2_1e7_second_iteration_on_the_updated_profile():
     """BASELINE config[2] at its own size WITH its own loop: iteration 1 of 10^7 protons through driver.run with smoothing on
     (K4 consumers on the device, iter_finalize, smooth_grid_par, new tables through mcs_set_grid), then iteration 2 -- on the
