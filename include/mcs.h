@@ -368,6 +368,15 @@ int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
  * 2 the one for electrons with radiative losses, 3 the fp32-state kernel, 4 its plain-loop form, 5 its specialisation for
  * electrons with radiative losses, 6 the common configuration with ion -> electron energy transfer on. */
 int mcs_set_tail_slicing(mcs_ctx* ctx, int budget_trips);
+/* A species' pcuts first .. last queued back to back: transport, pcut_finalize and new_pcut (src/cuts.jl:34-124) of every pcut with
+ * nothing read back in between -- n_saved, i_mult = max(n_target / n_saved, 1) (src/cuts.jl:42) and the size of the next population
+ * are decided on the device.  What the loop `for i_pcut` of src/main_loops.jl:184-292 + :293-330 does for ONE rank whose shard is
+ * the whole population (global indices 0, 1, 2, ...).  n_target[k]: target population after pcut first + k (N_PTS_PCUT or
+ * N_PTS_PCUT_HI).  Outputs (host arrays of last - first + 1 entries): population, saved particles and i_mult of every pcut, the
+ * kernel time of each transport launch (may be NULL).  Pcuts after one that saved nobody run on an empty population.  Per-particle
+ * results are those of the mcs_run_pcut / mcs_new_pcut sequence, bit for bit. */
+int mcs_run_pcuts_fused(mcs_ctx* ctx, int i_pcut_first, int i_pcut_last, const int64_t* n_target, int64_t* n_use, int64_t* n_saved,
+                        int64_t* i_mult, double* kernel_ms);
 int mcs_last_launches(mcs_ctx* ctx);
 int mcs_last_kernel(mcs_ctx* ctx);
 /* compute units of the context's device (the default grid of mcs_run_pcut* is 2 workgroups per CU; a caller that keeps two

@@ -20,6 +20,9 @@ size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
 int mcs_transport_max_entries(void);
 hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
 int mcs_transport_ws_threads(void);
+hipError_t mcs_launch_finalize_split_dev(const uint8_t* l_save, long long cap_n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                         unsigned long long* scan_total, long long* src, PcutDev* pd, PcutDev* pd_next, unsigned long long* counters,
+                                         long long n_target, unsigned long long* err, DevPop sv, DevPop out, int split_blocks, hipStream_t st);
 hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int kind, int blocks, int threads, hipStream_t st);
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
@@ -128,6 +131,10 @@ struct mcs_ctx {
   bool all_parallel = false;   // theta == 0 in every zone (mcs_set_grid)
   bool tail_merge = true;      // MCS_TAIL_MERGE=0: no consolidation of sparse waves (A/B measurements)
   int kernel_last = -1;        // mcs_last_kernel
+  // fused species loop (mcs_run_pcuts_fused): launch constants of every pcut (pinned + device), the per-pcut words decided on the
+  // device, one event pair per pcut
+  KArgs* h_fargs = nullptr; KArgs* d_fargs = nullptr; PcutDev* d_pd = nullptr; PcutDev* h_pd = nullptr; int fused_cap = 0;
+  std::vector<hipEvent_t> f_ev;
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
   bool k1_ws = false;          // MCS_K1_WS=1: the wave-specialised kernels (mcs_transport_ws.inc) where they apply -- measured at parity with
                                // transport_body in the bulk of a launch and behind it in the tail (profiles/r04_ws_kernel_ab.txt): off by default
@@ -347,6 +354,11 @@ int mcs_destroy(mcs_ctx* c) {
   if (c->own_I && c->d_I) (void)hipFree(c->d_I);
   if (c->h_args_pin) (void)hipHostFree(c->h_args_pin);
   if (c->h_back) (void)hipHostFree(c->h_back);
+  if (c->h_fargs) (void)hipHostFree(c->h_fargs);
+  if (c->h_pd) (void)hipHostFree(c->h_pd);
+  if (c->d_fargs) (void)hipFree(c->d_fargs);
+  if (c->d_pd) (void)hipFree(c->d_pd);
+  for (auto e : c->f_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -642,6 +654,50 @@ int mcs_run_pcut_indexed(mcs_ctx* c, int i_pcut, const int64_t* dev_gidx, int64_
   return run_pcut_impl(c, i_pcut, 0, 1, dev_gidx, n_saved);
 }
 
+// the launch constants of one pcut that do not depend on the kernel chosen (shared by mcs_run_pcut* and mcs_run_pcuts_fused)
+static void fill_kargs(mcs_ctx* c, KArgs& a, int i_pcut, long long n, long long i_prt_offset, long long i_prt_stride, const long long* dev_gidx, int budget) {
+  std::memset(&a, 0, sizeof(a));
+  a.P = c->P; a.L = c->L; a.tb = c->tb; a.in = c->cur.d; a.sv = c->sav.d; a.l_save = c->d_lsave;
+  a.T = c->d_T; a.I = c->d_I;
+  a.aa = c->aa; a.zzq = c->zzq; a.m = c->m; a.mc = c->mc; a.pmax_cutoff = c->pmax_cutoff; a.density = c->density; a.ewf = c->ewf;
+  a.inj_frac = c->h_inj_fracs[c->i_ion - 1];
+  a.pcut = c->h_pcuts[i_pcut - 1];
+  a.pcut_prev = i_pcut > 1 ? c->h_pcuts[i_pcut - 2] : 0.0;
+  a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
+  a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride; a.gidx = dev_gidx;
+  a.retro_cap = c->retro_cap;
+  a.defer_k = c->defer_k;
+  a.refill_min = c->refill_min;
+  // a wave whose live lanes all wait for company (fewer than defer_k of them) must be able to refill: with
+  // defer_k + refill_min <= 64 either defer_k lanes are live or refill_min are idle (see the deferral in transport_body)
+  if (a.defer_k > 64 - a.refill_min) a.defer_k = 64 - a.refill_min;
+  a.tail_ring = c->tail_ring ? 1 : 0;
+  // iseed_mod - i_prt, src/particle_loop.jl:35-40
+  a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
+                                     (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
+                                     (long long)(i_pcut - 1) * c->P.n_pts_max);
+  a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
+  a.tail_merge = c->tail_merge ? 1 : 0;
+  a.wait_full = c->park ? 1 : 0;
+  a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
+  if (c->debug_finals) { a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x; }
+  a.claim_max = 64; a.budget_trips = budget; a.strag_count = c->d_counters + 3;
+  a.strag_out = c->d_strag[0];
+}
+
+// which transport kernel a context's current species runs (mcs_launch_transport's `kind`), without the sliced / explicit-geometry cases
+static int species_kernel_kind(mcs_ctx* c, const KArgs& a, bool* ws_out) {
+  const bool plain_but_etf = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
+                             !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 && c->tb.n_xspec == 0 && !(a.inj_frac < 1);
+  const bool plain = plain_but_etf && !(c->P.energy_transfer_frac > 0);
+  const bool plain_etf = plain_but_etf && !plain;
+  const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
+  const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32;
+  if (ws_out) *ws_out = ws;
+  if (c->P.state_fp32) return c->f32_exact ? 3 : (c->f32_loop ? 1 : (lossy ? 2 : 0));
+  return ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)));
+}
+
 static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i_prt_stride, const int64_t* dev_gidx, int64_t* n_saved) {
   HIPCHK(hipSetDevice(c->device));
   if (i_prt_offset < 0 || i_prt_stride < 1) return fail("mcs_run_pcut: i_prt_first must be >= 0 and i_prt_stride >= 1");
@@ -668,33 +724,7 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   }
 
   KArgs& a = *c->h_args_pin;     // (every launch below is followed by a stream synchronisation before this is written again)
-  std::memset(&a, 0, sizeof(a));
-  a.P = c->P; a.L = c->L; a.tb = c->tb; a.in = c->cur.d; a.sv = c->sav.d; a.l_save = c->d_lsave;
-  a.T = c->d_T; a.I = c->d_I;
-  a.aa = c->aa; a.zzq = c->zzq; a.m = c->m; a.mc = c->mc; a.pmax_cutoff = c->pmax_cutoff; a.density = c->density; a.ewf = c->ewf;
-  a.inj_frac = c->h_inj_fracs[c->i_ion - 1];
-  a.pcut = c->h_pcuts[i_pcut - 1];
-  a.pcut_prev = i_pcut > 1 ? c->h_pcuts[i_pcut - 2] : 0.0;
-  a.i_iter = c->i_iter; a.i_ion = c->i_ion; a.i_pcut = i_pcut;
-  a.n = n; a.i_prt_offset = i_prt_offset; a.i_prt_stride = i_prt_stride; a.gidx = (const long long*)dev_gidx;
-  a.retro_cap = c->retro_cap;
-  a.defer_k = c->defer_k;
-  a.refill_min = c->refill_min;
-  // a wave whose live lanes all wait for company (fewer than defer_k of them) must be able to refill: with
-  // defer_k + refill_min <= 64 either defer_k lanes are live or refill_min are idle (see the deferral in transport_body)
-  if (a.defer_k > 64 - a.refill_min) a.defer_k = 64 - a.refill_min;
-  a.tail_ring = c->tail_ring ? 1 : 0;
-  // iseed_mod - i_prt, src/particle_loop.jl:35-40
-  a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
-                                     (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +
-                                     (long long)(i_pcut - 1) * c->P.n_pts_max);
-  a.work_counter = c->d_counters; a.n_saved = c->d_counters + 1;
-  a.tail_merge = c->tail_merge ? 1 : 0;
-  a.wait_full = c->park ? 1 : 0;
-  a.tally_rep = c->d_tally_rep; a.rep_n = c->d_tally_rep ? c->rep_n : 0;
-  if (c->debug_finals) { a.f_reason = c->f_reason; a.f_helix = c->f_helix; a.f_retro = c->f_retro; a.f_ptot = c->f_ptot; a.f_x = c->f_x; }
-  a.claim_max = 64; a.budget_trips = budget; a.strag_count = c->d_counters + 3;
-  a.strag_out = c->d_strag[0];
+  fill_kargs(c, a, i_pcut, n, i_prt_offset, i_prt_stride, (const long long*)dev_gidx, budget);
 
   const int threads = c->threads;
   int blocks = c->blocks;
@@ -801,6 +831,97 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // once miscompiled the l_save byte store, see csrc/Makefile)
   if (ns[0] != ns[1]) return fail("mcs_run_pcut: the kernel's n_saved counter and the count of l_save flags differ");
   if (n_saved) *n_saved = (int64_t)ns[0];
+  return 0;
+}
+
+// ---- A species' pcuts queued back to back (the device side of it): transport, pcut_finalize and new_pcut of every
+// pcut first .. last with NOTHING read back in between -- n_saved, i_mult = max(n_target / n_saved, 1) (src/cuts.jl:42) and the
+// size of the next population are decided on the device (mcs_k_pcut_decide) and the next launch reads its population size there.
+// One shard with global indices 0, 1, 2, ... (a single rank); not for sliced launches or an explicit launch geometry.
+// n_target[k]: the target population after pcut first + k.  Outputs (host, length last - first + 1): what mcs_run_pcut / mcs_new_pcut
+// would have returned per pcut, and each transport launch's kernel time.  Pcuts after the one that saved nobody run empty.
+int mcs_run_pcuts_fused(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const int64_t* n_target, int64_t* n_use_out, int64_t* n_saved_out,
+                        int64_t* i_mult_out, double* kernel_ms_out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->have_grid || !c->have_cuts) return fail("mcs_run_pcuts_fused: grid/cuts not set");
+  if (i_pcut_first < 1 || i_pcut_last > c->tb.n_pcuts || i_pcut_last < i_pcut_first) return fail("mcs_run_pcuts_fused: pcut range");
+  if (!n_target || !n_use_out || !n_saved_out || !i_mult_out) return fail("mcs_run_pcuts_fused: null argument");
+  if (c->tail_budget > 0 || c->claim_max_first < 64 || c->blocks > 0) return fail("mcs_run_pcuts_fused: not with sliced launches or an explicit launch geometry");
+  const int npc = i_pcut_last - i_pcut_first + 1;
+  long long cap_n = c->n;
+  for (int k = 0; k < npc; ++k) { if (n_target[k] < 1) return fail("mcs_run_pcuts_fused: n_target < 1"); if (n_target[k] > cap_n) cap_n = n_target[k]; }
+  // every population of the species fits: n_new = n_saved * (n_target / n_saved) <= max(n_target, n_saved)
+  if (ensure_capacity(c, cap_n)) return 1;
+  if (pop_alloc(c, c->spare, cap_n + cap_n / 8 + 1024)) return 1;
+  if (c->sav.cap < cap_n && pop_alloc(c, c->sav, cap_n + cap_n / 8 + 1024)) return 1;
+  if (npc > c->fused_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_fargs) (void)hipHostFree(c->h_fargs);
+    if (c->h_pd) (void)hipHostFree(c->h_pd);
+    if (c->d_fargs) (void)hipFree(c->d_fargs);
+    if (c->d_pd) (void)hipFree(c->d_pd);
+    HIPCHK(hipHostMalloc((void**)&c->h_fargs, sizeof(KArgs) * (size_t)npc));
+    HIPCHK(hipHostMalloc((void**)&c->h_pd, sizeof(PcutDev) * (size_t)(npc + 1)));
+    HIPCHK(hipMalloc((void**)&c->d_fargs, sizeof(KArgs) * (size_t)npc));
+    HIPCHK(hipMalloc((void**)&c->d_pd, sizeof(PcutDev) * (size_t)(npc + 1)));
+    while ((int)c->f_ev.size() < 2 * npc) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->f_ev.push_back(e); }
+    c->fused_cap = npc;
+  }
+  // launch constants of every pcut: the buffers rotate (cur -> saved -> spare -> cur) independently of the sizes
+  PopBuf cur = c->cur, spare = c->spare;
+  int kind = 0, blocks = 0, threads = c->threads;
+  bool ws = false;
+  for (int k = 0; k < npc; ++k) {
+    KArgs& a = c->h_fargs[k];
+    fill_kargs(c, a, i_pcut_first + k, 0, 0, 1, nullptr, 0);
+    a.in = cur.d; a.sv = c->sav.d;
+    a.n_dev = &c->d_pd[k].n_use;
+    if (k == 0) {
+      kind = species_kernel_kind(c, a, &ws);
+      if (ws) { threads = mcs_transport_ws_threads(); blocks = c->n_cu; }
+      else { threads = 256; blocks = c->n_cu * (c->P.state_fp32 ? ((c->f32_loop || c->f32_exact) ? 3 : c->f32_blocks_per_cu) : 2); }
+      const long long want = (cap_n + threads - 1) / threads;
+      if (want < blocks) blocks = (int)(want > 0 ? want : 1);
+    }
+    if (ws) { a.ws_pop_max = c->ws_pop_max > 0 ? c->ws_pop_max : threads + 160; a.ws_serve_min = c->ws_serve_min; }
+    PopBuf t = cur; cur = spare; spare = t;
+  }
+  std::memset(c->h_pd, 0, sizeof(PcutDev) * (size_t)(npc + 1));
+  c->h_pd[0].n_use = c->n;
+  HIPCHK(hipMemcpyAsync(c->d_fargs, c->h_fargs, sizeof(KArgs) * (size_t)npc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PcutDev) * (size_t)(npc + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  const int split_blocks = (int)std::min<long long>((cap_n + 255) / 256, (long long)c->n_cu * 16);
+  cur = c->cur; spare = c->spare;
+  for (int k = 0; k < npc; ++k) {
+    HIPCHK(hipMemsetAsync(c->d_lsave, 0, (size_t)cap_n, c->stream));
+    HIPCHK(hipEventRecord(c->f_ev[2 * k], c->stream));
+    if (c->P.state_fp32) HIPCHK(mcs_launch_transport_f32(c->d_fargs + k, kind, blocks, 256, c->stream));
+    else HIPCHK(mcs_launch_transport(c->d_fargs + k, kind, blocks, threads, c->stream));
+    HIPCHK(hipEventRecord(c->f_ev[2 * k + 1], c->stream));
+    HIPCHK(mcs_launch_finalize_split_dev(c->d_lsave, cap_n, c->d_bcounts, c->d_boffs, c->d_counters + 2, c->d_src, c->d_pd + k, c->d_pd + k + 1,
+                                         c->d_counters, (long long)n_target[k], c->d_counters + 4, c->sav.d, spare.d, split_blocks, c->stream));
+    PopBuf t = cur; cur = spare; spare = t;
+  }
+  c->rep_dirty = true;
+  HIPCHK(hipMemcpyAsync(c->h_pd, c->d_pd, sizeof(PcutDev) * (size_t)(npc + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_back, c->d_counters + 3, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->h_back[1] != 0) return fail("mcs_run_pcuts_fused: the kernel's n_saved counter and the count of l_save flags differ");
+  if (ws && c->h_back[0] != 0) return fail("mcs_run_pcuts_fused: a bounded wait of the wave-specialised kernel ran out (a launch is incomplete)");
+  double ms_sum = 0.0;
+  for (int k = 0; k < npc; ++k) {
+    n_use_out[k] = c->h_pd[k].n_use; n_saved_out[k] = c->h_pd[k].n_saved; i_mult_out[k] = c->h_pd[k].i_mult;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->f_ev[2 * k], c->f_ev[2 * k + 1]));
+    if (kernel_ms_out) kernel_ms_out[k] = ms;
+    ms_sum += ms;
+  }
+  c->cur = cur; c->spare = spare;
+  c->n = c->h_pd[npc].n_use;
+  c->n_run_last = -1; c->n_saved_last = 0;
+  c->last_ms = ms_sum; c->tail_rounds_last = npc;
+  c->kernel_last = c->P.state_fp32 ? (c->f32_exact ? 9 : (c->f32_loop ? 4 : (kind == 2 ? 5 : 3))) : kind;
   return 0;
 }
 

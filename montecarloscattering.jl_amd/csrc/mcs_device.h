@@ -40,6 +40,8 @@ struct KArgs {
   double pcut, pcut_prev;
   int i_iter, i_ion, i_pcut;
   long long n;               // local population size
+  const long long* n_dev;    // or, when not null: where the population size is read from on the device (mcs_run_pcuts_fused: the host
+                             // does not know it -- i_mult and the size of the next population are decided on the device)
   long long i_prt_offset;    // global i_prt of local particle 0, minus 1
   long long i_prt_stride;    // global i_prt of local particle k = i_prt_offset + 1 + k * i_prt_stride (1: a contiguous shard)
   const long long* gidx;     // or, when not null: global 0-based index of local particle k (mcs_run_pcut_indexed); i_prt = gidx[k] + 1
@@ -79,6 +81,9 @@ struct KArgs {
 #ifndef MCS_TALLY_REPLICAS
 #define MCS_TALLY_REPLICAS 16
 #endif
+
+// One pcut of a fused species loop (mcs_run_pcuts_fused): what the host would have read back after every pcut
+struct PcutDev { long long n_use, n_saved, i_mult, n_new; };
 
 // zone-crossing tally records staged in LDS by the transport kernel
 #define MCS_EV_F64 8         // pb_pf, p_perp, ptot_pf, gam_pf, phi, weight, x, x_old

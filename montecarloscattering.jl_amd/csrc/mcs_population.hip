@@ -114,6 +114,87 @@ mcs_k_compact_index(const uint8_t* __restrict__ l_save, long long n, const unsig
   }
 }
 
+// ---- the same three steps and the split with the population size ON THE DEVICE (mcs_run_pcuts_fused: a species' pcuts are
+// queued back to back, nothing is read back in between).  Grids are sized for the capacity; blocks beyond the population count 0.
+extern "C" __global__ void __launch_bounds__(256)
+mcs_k_count_saved_dev(const uint8_t* __restrict__ l_save, const PcutDev* __restrict__ pd, unsigned int* __restrict__ block_counts) {
+  __shared__ unsigned int wsum[4];
+  const long long n = pd->n_use;
+  const long long base = (long long)blockIdx.x * 1024;
+  unsigned int c = 0;
+  if (base < n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long i = base + r * 256 + threadIdx.x;
+      const bool f = i < n && l_save[i] == 1;
+      c += (unsigned int)__popcll(__ballot(f));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+extern "C" __global__ void __launch_bounds__(256)
+mcs_k_compact_index_dev(const uint8_t* __restrict__ l_save, const PcutDev* __restrict__ pd, const unsigned long long* __restrict__ offsets,
+                        long long* __restrict__ src) {
+  __shared__ unsigned int wcount[4][4];
+  const long long n = pd->n_use;
+  const long long base = (long long)blockIdx.x * 1024;
+  if (base >= n) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  bool f[4];
+  unsigned long long m[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long i = base + r * 256 + threadIdx.x;
+    f[r] = i < n && l_save[i] == 1;
+    m[r] = __ballot(f[r]);
+    if (lane == 0) wcount[r][wave] = (unsigned int)__popcll(m[r]);
+  }
+  __syncthreads();
+  unsigned long long run = offsets[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned long long before = run;
+    for (int w = 0; w < wave; ++w) before += wcount[r][w];
+    if (f[r]) {
+      const unsigned long long rank = before + (unsigned long long)__popcll(m[r] & ((1ull << lane) - 1ull));
+      src[rank] = base + r * 256 + threadIdx.x;
+    }
+    run += wcount[r][0] + wcount[r][1] + wcount[r][2] + wcount[r][3];
+  }
+}
+// pcut_finalize + the head of new_pcut on the device (src/cuts.jl:100-124, :42): n_saved from the flags (cross-checked against the
+// transport kernel's own counter), i_mult = max(n_target / n_saved, 1), the size of the next population; the next launch's work
+// counter and n_saved counter are cleared here.  One thread.
+extern "C" __global__ void mcs_k_pcut_decide(PcutDev* __restrict__ pd, PcutDev* __restrict__ pd_next, const unsigned long long* __restrict__ scan_total,
+                                             unsigned long long* __restrict__ counters /*[0] work, [1] n_saved (K1)*/, long long n_target,
+                                             unsigned long long* __restrict__ err) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long ns = (long long)*scan_total;
+  if ((unsigned long long)ns != counters[1]) atomicAdd(err, 1ull);      // (a spilling build once miscompiled the l_save store: csrc/Makefile)
+  const long long im = ns > 0 ? (n_target / ns > 1 ? n_target / ns : 1) : 1;
+  pd->n_saved = ns; pd->i_mult = im; pd->n_new = ns * im;
+  if (pd_next) pd_next->n_use = ns * im;
+  counters[0] = 0ull; counters[1] = 0ull;
+}
+extern "C" __global__ void __launch_bounds__(256)
+mcs_k_split_dev(DevPop sv, DevPop out, const long long* __restrict__ src, const PcutDev* __restrict__ pd) {
+  const long long n_new = pd->n_new, i_mult = pd->i_mult;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n_new; o += (long long)gridDim.x * blockDim.x) {
+    const long long j = src[o / i_mult];
+    out.weight[o] = sv.weight[j] / (double)i_mult;
+    out.ptot_pf[o] = sv.ptot_pf[j];
+    out.pb_pf[o] = sv.pb_pf[j];
+    out.x_PT_cm[o] = sv.x_PT_cm[j];
+    out.xn_per[o] = sv.xn_per[j];
+    out.prp_x_cm[o] = sv.prp_x_cm[j];
+    out.acctime_sec[o] = sv.acctime_sec[j];
+    out.phi_rad[o] = sv.phi_rad[j];
+    out.meta[o] = sv.meta[j];
+  }
+}
+
 // K2d: new[o] = saved[src[o / i_mult]], weight / i_mult  (src/cuts.jl:66-92)
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_split(DevPop sv, DevPop out, const long long* __restrict__ src, long long n_new, long long i_mult) {
@@ -266,6 +347,18 @@ hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* 
   hipLaunchKernelGGL(mcs_k_count_saved, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_counts);
   hipLaunchKernelGGL(mcs_k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets, total_dev);
   hipLaunchKernelGGL(mcs_k_compact_index, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_offsets, src);
+  return hipGetLastError();
+}
+// one pcut's pcut_finalize + new_pcut with the sizes on the device (see mcs_k_pcut_decide); cap_n: the largest population possible
+hipError_t mcs_launch_finalize_split_dev(const uint8_t* l_save, long long cap_n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                         unsigned long long* scan_total, long long* src, PcutDev* pd, PcutDev* pd_next, unsigned long long* counters,
+                                         long long n_target, unsigned long long* err, DevPop sv, DevPop out, int split_blocks, hipStream_t st) {
+  const long long nb = (cap_n + 1023) / 1024;
+  hipLaunchKernelGGL(mcs_k_count_saved_dev, dim3((unsigned)nb), dim3(256), 0, st, l_save, pd, block_counts);
+  hipLaunchKernelGGL(mcs_k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets, scan_total);
+  hipLaunchKernelGGL(mcs_k_compact_index_dev, dim3((unsigned)nb), dim3(256), 0, st, l_save, pd, block_offsets, src);
+  hipLaunchKernelGGL(mcs_k_pcut_decide, dim3(1), dim3(64), 0, st, pd, pd_next, scan_total, counters, n_target, err);
+  hipLaunchKernelGGL(mcs_k_split_dev, dim3((unsigned)split_blocks), dim3(256), 0, st, sv, out, src, pd);
   return hipGetLastError();
 }
 hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st) {

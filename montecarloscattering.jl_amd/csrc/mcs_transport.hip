@@ -1698,7 +1698,12 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   // fresh_lo .. n-1 of the population (see KArgs: sliced launches)
   const unsigned long long n_resume = SLICED ? (unsigned long long)a->n_resume : 0ull;
   const long long fresh_lo = SLICED ? a->fresh_lo : 0ll;
-  const unsigned long long n = n_resume + (unsigned long long)(a->n - fresh_lo);
+  long long n_pop = a->n;
+  if (a->n_dev) {      // (fused species loop: the size was decided on the device; one load, made wave-uniform)
+    const long long v = *a->n_dev;
+    n_pop = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  }
+  const unsigned long long n = n_resume + (unsigned long long)(n_pop - fresh_lo);
   const unsigned budget = SLICED ? (unsigned)__builtin_amdgcn_readfirstlane(a->budget_trips) : 0u;
   const int claim_max = SLICED ? __builtin_amdgcn_readfirstlane(a->claim_max) : 64;
   unsigned mtick_ex = 0;            // mtick when this wave found the queue exhausted

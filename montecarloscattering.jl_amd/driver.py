@@ -31,6 +31,7 @@ fluxes) live on rank 0 only so that the sum over ranks is the single-GPU result.
 from __future__ import annotations
 
 import dataclasses
+import os
 import time
 from typing import Callable, List, Optional
 
@@ -132,7 +133,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
         first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True,
-        before_pcut: Optional[Callable] = None, tcut_print: bool = False) -> RunResult:
+        before_pcut: Optional[Callable] = None, tcut_print: bool = False, fused_pcuts: bool = True) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -244,7 +245,24 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 backend.init_pop(inj, first, n_local, n_total, stride)
             p_pcut_hi = inputs.pcut_hi(cfg.EN_PCUT_HI, sp.mass)
             n_use_global = n_total
-            for i_pcut in range(1, n_pcuts + 1):
+            # One rank, no per-pcut hook: the whole pcut loop of the species is queued on the device at once -- n_saved, i_mult and
+            # the next population's size are decided there (mcs_run_pcuts_fused), one read-back per species instead of one per pcut.
+            fused = (fused_pcuts and not multi and before_pcut is None and hasattr(backend, "run_pcuts_fused") and n_pcuts >= 1
+                     and os.environ.get("MCS_FUSED_PCUTS", "1") != "0")
+            if fused:
+                t0 = time.perf_counter()
+                targets = [cfg.N_PTS_PCUT if prob.pcuts[ip - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI for ip in range(1, n_pcuts + 1)]
+                n_use_a, n_saved_a, i_mult_a, ms_a = backend.run_pcuts_fused(1, n_pcuts, targets)
+                wall = (time.perf_counter() - t0) * 1e3
+                for ip in range(1, n_pcuts + 1):
+                    nu, nsv, im = int(n_use_a[ip - 1]), int(n_saved_a[ip - 1]), int(i_mult_a[ip - 1])
+                    last = nsv == 0 or ip == n_pcuts
+                    stats.append(PcutStat(i_iter, i_ion, ip, nu, nsv, im if nsv > 0 else 0, nu, "-", float(ms_a[ip - 1]), wall / n_pcuts))
+                    if verbose and is_root:
+                        print(f"[iter {i_iter} ion {i_ion} pcut {ip:2d}] n_use={nu} n_saved={nsv} i_mult={im} kernel={ms_a[ip - 1]:.2f} ms (fused loop)", flush=True)
+                    if last:
+                        break
+            for i_pcut in (() if fused else range(1, n_pcuts + 1)):
                 t0 = time.perf_counter()
                 if before_pcut is not None:
                     before_pcut(i_iter, i_ion, i_pcut)

@@ -257,6 +257,18 @@ class HipBackend:
         self._chk(self.lib.mcs_read_tallies_part(self.h, first, tail.size, _dp(tail), i.ctypes.data_as(c_int64_p)))
         return f, i
 
+    def run_pcuts_fused(self, i_pcut_first: int, i_pcut_last: int, n_target):
+        """mcs_run_pcuts_fused: the pcuts first .. last of the current species queued back to back, n_saved / i_mult / the next
+        population's size decided on the device -> (n_use, n_saved, i_mult, kernel_ms) per pcut.  MCS_FUSED_PCUTS=0: not offered."""
+        npc = i_pcut_last - i_pcut_first + 1
+        tg = np.ascontiguousarray(n_target, dtype=np.int64)
+        assert tg.shape == (npc,)
+        nu, ns, im = (np.zeros(npc, dtype=np.int64) for _ in range(3))
+        ms = np.zeros(npc)
+        self._chk(self.lib.mcs_run_pcuts_fused(self.h, int(i_pcut_first), int(i_pcut_last), tg.ctypes.data_as(c_int64_p), nu.ctypes.data_as(c_int64_p),
+                                               ns.ctypes.data_as(c_int64_p), im.ctypes.data_as(c_int64_p), _dp(ms)))
+        return nu, ns, im, ms
+
     def read_counters(self):
         """The int64 tallies alone (num_crossings + event counters: ~1 KB), no fp64 word."""
         i = np.zeros(self.layout.n_i64, dtype=np.int64)

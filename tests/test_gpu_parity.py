@@ -1245,3 +1245,33 @@ def test_fp32_hardware_primitives_against_the_exact_build(monkeypatch):
     scale = np.abs(se).max()
     noise = np.abs(s2 - se).max() / scale
     assert np.abs(sh - se).max() / scale < max(3 * noise, 1e-3), (np.abs(sh - se).max() / scale, noise)
+
+
+@pytest.mark.parametrize("case", ["protons", "mixed_species", "fp32_state"])
+def test_fused_pcut_loop_equals_per_pcut_calls(case):
+    """mcs_run_pcuts_fused queues a species' whole pcut loop on the device: n_saved (count of the l_save flags, cross-checked
+    against the kernel's own counter on the device), i_mult = max(n_target / n_saved, 1) (src/cuts.jl:42) and the size of the next
+    population are decided there, the next transport launch reads its population size from device memory -- one read-back per
+    species instead of one per pcut.  Through the same driver with and without it: the same populations, saved counts and i_mult in
+    every pcut, the same integer tallies, binned tallies up to add order; the final populations are equal bit for bit."""
+    kw = {}
+    if case == "mixed_species":
+        kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1),
+                           mcs.inputs.Species(mcs.constants.ME / mcs.constants.MP, -1.0, 1e6, 1.2)], energy_transfer_frac=0.1, radiation_losses=True)
+    if case == "fp32_state":
+        kw = dict(state_fp32=True)
+    N = 30000
+    res = []
+    for fused in (True, False):
+        prob = make_problem(N, **kw)
+        hb = hip_backend(prob)
+        r = mcs.driver.run(prob, hb, None, n_itrs=1, fused_pcuts=fused)
+        res.append((r, hb.get_population(), hb.layout))
+        hb.destroy()
+    (ra, pa, L), (rb, pb, _) = res
+    sa = [(s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in ra.stats]
+    sb = [(s.i_ion, s.i_pcut, s.n_pts_use, s.n_saved, s.i_mult) for s in rb.stats]
+    assert sa == sb and len(sa) >= 20
+    assert np.array_equal(ra.tallies_i64, rb.tallies_i64)
+    assert_tallies_close(L, ra.tallies_f64, rb.tallies_f64, TALLY_RTOL)
+    assert all(s.kernel_ms > 0 for s in ra.stats)
