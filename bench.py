@@ -242,8 +242,10 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - marks["t0"]
     steps_total = marks[n_itrs][1] - (marks[args.warmup][1] if args.warmup > 0 else 0)
-    kern_ms = sum(s.kernel_ms for s in res.stats if s.i_iter > args.warmup)
-    n_launch = sum(1 for s in res.stats if s.i_iter > args.warmup)
+    # every transport launch of the timed iterations, the ones a fused species loop makes on an empty population included (they
+    # are launches of the same kernel: the rocprofv3 kernel trace averages over them too)
+    kern_ms = sum(s.kernel_ms for s in res.stats if s.i_iter > args.warmup) + sum(e[3] for e in res.empty_launches if e[0] > args.warmup)
+    n_launch = sum(1 for s in res.stats if s.i_iter > args.warmup) + sum(1 for e in res.empty_launches if e[0] > args.warmup)
     # local steps of this rank in the timed region (for the per-kernel roofline)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -253,7 +255,7 @@ def main():
     # HBM bytes per K1 launch: NOT measured by this process -- the committed result of the separate
     # `rocprofv3 --pmc` passes over this same command (tools/profile_bench.sh), labelled as such
     traffic, traffic_src = None, None
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["hbm_bytes_per_launch"]

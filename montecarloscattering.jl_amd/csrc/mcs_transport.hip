@@ -1625,6 +1625,7 @@ __device__ __forceinline__ void block_flush(CK* a) {
 template <bool PLAIN, bool LOSSY = false, bool PLAIN_ETF = false, bool SLICED = false>
 __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   CK* a = (CK*)ka;
+  if (a->n_dev && *a->n_dev == 0) return;      // (a fused species loop launches the pcuts after the last populated one too)
   const int ne = a->P.n_grid + 2, ng = a->P.n_grid, ntc = a->tb.n_tcuts;
   block_prologue(a);
   __syncthreads();

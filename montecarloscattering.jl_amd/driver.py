@@ -66,6 +66,8 @@ class RunResult:
     iter_finals: list = dataclasses.field(default_factory=list)   # [(i_iter, IterFinal, IonFinal)] when run(finalize=True)
     iter_state: object = None     # iter_finalize.IterState after the last iteration (run(finalize=True))
     local_steps: list = dataclasses.field(default_factory=list)   # [(i_iter, i_ion, helix + retro steps made by THIS rank's kernels)]
+    empty_launches: list = dataclasses.field(default_factory=list)   # [(i_iter, i_ion, i_pcut, kernel_ms)]: transport launches of a fused species
+                                                                  # loop on an EMPTY population (the pcuts after the one that saved nobody)
 
 
 class Comm:
@@ -191,6 +193,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         _i0 = backend.read_counters() if hasattr(backend, "read_counters") else backend.read_tallies()[1]
         steps_seen = int(_i0[i_h] + _i0[i_r])
     iter_finals = []
+    empty_launches = []
     if smoothing is not None:
         finalize = True
     if finalize:
@@ -252,15 +255,26 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             if fused:
                 t0 = time.perf_counter()
                 targets = [cfg.N_PTS_PCUT if prob.pcuts[ip - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI for ip in range(1, n_pcuts + 1)]
-                n_use_a, n_saved_a, i_mult_a, ms_a = backend.run_pcuts_fused(1, n_pcuts, targets)
+                # (in chunks: a species that ends early -- the thermal electrons in their first pcut -- would otherwise pay ~35 us of
+                # empty launches for every remaining pcut; one read-back per chunk of 12 instead of one per pcut)
+                chunk = max(1, int(os.environ.get("MCS_FUSED_CHUNK", "12")))
+                n_use_a, n_saved_a, i_mult_a, ms_a = [], [], [], []
+                for c0 in range(1, n_pcuts + 1, chunk):
+                    c1 = min(c0 + chunk - 1, n_pcuts)
+                    a_, b_, c_, d_ = backend.run_pcuts_fused(c0, c1, targets[c0 - 1:c1])
+                    n_use_a.extend(a_); n_saved_a.extend(b_); i_mult_a.extend(c_); ms_a.extend(d_)
+                    if min(b_) == 0:
+                        break
+                n_done = len(n_use_a)
                 wall = (time.perf_counter() - t0) * 1e3
-                for ip in range(1, n_pcuts + 1):
+                for ip in range(1, n_done + 1):
                     nu, nsv, im = int(n_use_a[ip - 1]), int(n_saved_a[ip - 1]), int(i_mult_a[ip - 1])
                     last = nsv == 0 or ip == n_pcuts
-                    stats.append(PcutStat(i_iter, i_ion, ip, nu, nsv, im if nsv > 0 else 0, nu, "-", float(ms_a[ip - 1]), wall / n_pcuts))
+                    stats.append(PcutStat(i_iter, i_ion, ip, nu, nsv, im if nsv > 0 else 0, nu, "-", float(ms_a[ip - 1]), wall / max(n_done, 1)))
                     if verbose and is_root:
                         print(f"[iter {i_iter} ion {i_ion} pcut {ip:2d}] n_use={nu} n_saved={nsv} i_mult={im} kernel={ms_a[ip - 1]:.2f} ms (fused loop)", flush=True)
                     if last:
+                        empty_launches.extend((i_iter, i_ion, jp, float(ms_a[jp - 1])) for jp in range(ip + 1, n_done + 1))
                         break
             for i_pcut in (() if fused else range(1, n_pcuts + 1)):
                 t0 = time.perf_counter()
@@ -424,7 +438,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     from .capi import IC
     return RunResult(G_f, G_i, per_species, stats,
                      int(G_i[ng + IC["STEPS_HELIX"]]), int(G_i[ng + IC["STEPS_RETRO"]]), iter_finals,
-                     it_state if finalize else None, local_steps)
+                     it_state if finalize else None, local_steps, empty_launches)
 
 
 # The never-reset tallies of the reference (esc_flux, esc_*_eff, spectra_coupled, spectra_sf / _pf accumulate over

@@ -17,7 +17,7 @@ def wrap(obj, name):
     def g(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); acc[name] += time.perf_counter() - t; cnt[name] += 1; return r
     setattr(obj, name, g)
-for name in ("begin_iteration", "begin_species", "set_fluxes", "init_pop", "run_pcut", "new_pcut", "read_tallies_light", "read_tallies",
+for name in ("begin_iteration", "begin_species", "set_fluxes", "init_pop", "run_pcut", "run_pcuts_fused", "new_pcut", "read_tallies_light", "read_tallies", "read_counters",
              "dndp_cr", "thermo_calcs", "set_grid", "set_cuts"):
     wrap(hb, name)
 itf = m.iter_finalize
@@ -36,4 +36,5 @@ print(f"N = {N}: wall {wall:.2f} ms per iteration, K1 kernels (HIP events) {kern
 tot = 0.0
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"   {k:28s} {v/NIT*1e3:8.3f} ms per iteration in {cnt[k]//NIT:3d} calls"); tot += v
-print(f"   {'sum of the above':28s} {tot/NIT*1e3:8.3f} ms;  run_pcut wall - K1 kernel time = {acc['run_pcut']/NIT*1e3 - kern:.3f} ms")
+print(f"   {'sum of the above':28s} {tot/NIT*1e3:8.3f} ms;  (run_pcut + run_pcuts_fused) wall - K1 kernel time = {(acc['run_pcut'] + acc['run_pcuts_fused'])/NIT*1e3 - kern:.3f} ms"
+      f"   [MCS_FUSED_PCUTS={os.environ.get('MCS_FUSED_PCUTS', '1')}]")
