@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void block_prologue(CK* a) {
 #endif
 #endif
   if (threadIdx.x < 2) { S_mstate[threadIdx.x] = 0u; S_mcount[threadIdx.x] = 0u; }
-  if ((threadIdx.x & 63u) == 0u) S_msimd[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  if ((threadIdx.x & 63u) == 0u && threadIdx.x < 256u) S_msimd[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);     // (four entries: the wave-specialised kernel runs this prologue with eight waves)
 #ifdef MCS_PROF
   if (threadIdx.x < MCS_NPROF) S_prof[threadIdx.x] = 0ull;
 #endif
