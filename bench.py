@@ -131,7 +131,15 @@ def workload_label(args):
             f"iter_finalize" + (" + profile update" if args.smooth else "") + ")")
 
 
-def kernel_label(args):
+KERNEL_NAMES = {0: "mcs_k_transport", 1: "mcs_k_transport_plain", 2: "mcs_k_transport_lossy", 3: "mcs_k_transport_f32", 4: "mcs_k_transport_f32_loop",
+                5: "mcs_k_transport_f32_lossy", 6: "mcs_k_transport_plain_etf", 7: "mcs_k_transport_ws", 8: "mcs_k_transport_ws_etf",
+                9: "mcs_k_transport_f32_loop_exact", 10: "mcs_k_transport_sliced"}
+
+
+def kernel_label(args, last_kernel=None):
+    if last_kernel in (7, 8) and not args.mixed and not args.fp32:
+        return (KERNEL_NAMES[last_kernel] + " (the wave-specialised form of the common configuration's kernel: the library picks it for populations of "
+                "at least MCS_WS_AUTO_MIN = 6e6 particles, mcs_k_transport_plain below; mcs_last_kernel of the last launch)")
     if args.fp32:
         return "mcs_k_transport_f32" + (" (ions) + mcs_k_transport_f32_lossy (electrons)" if args.mixed else "") + ": the fp32-state variant; priced against the fp64 peak by the same 400-flop weight"
     if args.mixed:
@@ -283,7 +291,7 @@ def main():
                        "parallelism": f"interleaved particle shards x{world}; per pcut all-gather(n_saved) + all-gather(saved global indices, 4 B each) [or of the saved particles when few]; all-reduce(tallies) per species"},
             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_label(args), "launches": n_launch,
+                         "kernel": kernel_label(args, be.last_kernel()), "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1),
                          "kernel_steps_per_s": local_steps / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                          "note": "400 algorithmic fp64 flop/step (SURVEY 8d) x steps / HIP-event kernel time; "

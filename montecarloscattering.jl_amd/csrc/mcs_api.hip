@@ -136,8 +136,10 @@ struct mcs_ctx {
   KArgs* h_fargs = nullptr; KArgs* d_fargs = nullptr; PcutDev* d_pd = nullptr; PcutDev* h_pd = nullptr; int fused_cap = 0;
   std::vector<hipEvent_t> f_ev;
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
-  bool k1_ws = false;          // MCS_K1_WS=1: the wave-specialised kernels (mcs_transport_ws.inc) where they apply -- measured at parity with
-                               // transport_body in the bulk of a launch and behind it in the tail (profiles/r04_ws_kernel_ab.txt): off by default
+  int k1_ws = 2;               // the wave-specialised kernels (mcs_transport_ws.inc), where they apply: MCS_K1_WS=1 always, =0 never, default (2)
+                               // for populations of at least ws_auto_min particles -- measured level with transport_body at 4e6 particles, 3.8 %
+                               // faster at 1e7 and 7 % slower at 2e6, where its missing tail consolidation shows (profiles/r04_ws_kernel_ab.txt)
+  long long ws_auto_min = 6000000;   // MCS_WS_AUTO_MIN=<n>
   int ws_pop_max = 0;          // MCS_WS_POP=<n>: particles a block of the wave-specialised kernel holds at most (0: lanes + 160)
   int ws_serve_min = 64;       // MCS_WS_SERVE=<n>: pending particles at which a wave serves them
   // consumers (K4): table staging, outputs, thermo scratch slab
@@ -293,7 +295,8 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   } while (0)
   { const char* e = std::getenv("MCS_FORCE_GENERAL"); c->force_general = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_TAIL_MERGE"); c->tail_merge = !(e && e[0] == '0'); }
-  { const char* e = std::getenv("MCS_K1_WS"); c->k1_ws = e && e[0] == '1'; }
+  { const char* e = std::getenv("MCS_K1_WS"); c->k1_ws = !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }
+  { const char* e = std::getenv("MCS_WS_AUTO_MIN"); if (e && std::atoll(e) >= 0) c->ws_auto_min = std::atoll(e); }
   { const char* e = std::getenv("MCS_WS_POP"); if (e && std::atoi(e) >= 64 && std::atoi(e) <= 4096) c->ws_pop_max = std::atoi(e); }
   { const char* e = std::getenv("MCS_WS_SERVE"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->ws_serve_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
@@ -686,13 +689,13 @@ static void fill_kargs(mcs_ctx* c, KArgs& a, int i_pcut, long long n, long long 
 }
 
 // which transport kernel a context's current species runs (mcs_launch_transport's `kind`), without the sliced / explicit-geometry cases
-static int species_kernel_kind(mcs_ctx* c, const KArgs& a, bool* ws_out) {
+static int species_kernel_kind(mcs_ctx* c, const KArgs& a, long long n, bool* ws_out) {
   const bool plain_but_etf = !c->force_general && c->all_parallel && !c->P.dont_scatter && !c->P.use_custom_epsB &&
                              !c->P.dont_DSA && !(c->P.feb_downstream > 0) && c->aa >= 1 && c->tb.n_xspec == 0 && !(a.inj_frac < 1);
   const bool plain = plain_but_etf && !(c->P.energy_transfer_frac > 0);
   const bool plain_etf = plain_but_etf && !plain;
   const bool lossy = !c->force_general && c->P.do_rad_losses && c->aa < 1 && !c->P.use_custom_epsB && !c->P.dont_scatter;
-  const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32;
+  const bool ws = (c->k1_ws == 1 || (c->k1_ws == 2 && n >= c->ws_auto_min)) && (plain || plain_etf) && !c->P.state_fp32;
   if (ws_out) *ws_out = ws;
   if (c->P.state_fp32) return c->f32_exact ? 3 : (c->f32_loop ? 1 : (lossy ? 2 : 0));
   return ws ? (plain ? 7 : 8) : (plain ? 1 : (lossy ? 2 : (plain_etf ? 6 : 0)));
@@ -755,7 +758,8 @@ static int run_pcut_impl(mcs_ctx* c, int i_pcut, int64_t i_prt_offset, int64_t i
   // sliced launches (suspend / resume, fewer than 64 particles per wave) run the general kernel's SLICED form
   const bool sliced = !c->P.state_fp32 && (budget > 0 || c->claim_max_first < 64);
   // the wave-specialised form of those two (mcs_transport_ws.inc): 512-thread blocks, one per CU
-  const bool ws = c->k1_ws && (plain || plain_etf) && !c->P.state_fp32 && budget == 0 && c->claim_max_first == 64 && c->blocks <= 0;
+  const bool ws = (c->k1_ws == 1 || (c->k1_ws == 2 && n >= c->ws_auto_min)) && (plain || plain_etf) && !c->P.state_fp32 && budget == 0 &&
+                  c->claim_max_first == 64 && c->blocks <= 0;
   int k1_threads = threads;
   if (ws) {
     k1_threads = mcs_transport_ws_threads();
@@ -877,7 +881,7 @@ int mcs_run_pcuts_fused(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const int
     a.in = cur.d; a.sv = c->sav.d;
     a.n_dev = &c->d_pd[k].n_use;
     if (k == 0) {
-      kind = species_kernel_kind(c, a, &ws);
+      kind = species_kernel_kind(c, a, cap_n, &ws);
       if (ws) { threads = mcs_transport_ws_threads(); blocks = c->n_cu; }
       else { threads = 256; blocks = c->n_cu * (c->P.state_fp32 ? ((c->f32_loop || c->f32_exact) ? 3 : c->f32_blocks_per_cu) : 2); }
       const long long want = (cap_n + threads - 1) / threads;

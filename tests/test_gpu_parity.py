@@ -510,6 +510,23 @@ def test_wave_specialised_kernel_is_bit_identical(monkeypatch, case, N):
     assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
 
 
+def test_wave_specialised_kernel_is_picked_by_population_size(monkeypatch):
+    """Without MCS_K1_WS the library picks the wave-specialised kernel for launches of at least MCS_WS_AUTO_MIN particles (6e6: it is
+    level with the lane-owns-particle kernel at 4e6 and 3.8 % faster at 1e7, profiles/r04_ws_kernel_ab.txt) and the lane-owns-particle
+    kernel below -- per launch, so a species whose population shrinks changes kernel on the way; the fused species loop decides by the
+    largest population its chunk can hold.  The 1e7 and 5e7 tests of tests/test_gpu_full_size.py therefore run through it by default."""
+    monkeypatch.delenv("MCS_K1_WS", raising=False)
+    prob = make_problem(30000)
+    for auto_min, want in (("20000", 7), ("40000", 1), (None, 1)):
+        if auto_min is None: monkeypatch.delenv("MCS_WS_AUTO_MIN", raising=False)
+        else: monkeypatch.setenv("MCS_WS_AUTO_MIN", auto_min)
+        hb = hip_backend(prob)
+        start_species(hb, prob)
+        hb.run_pcut(1, 0)
+        assert hb.last_kernel() == want, (auto_min, hb.last_kernel())
+        hb.destroy()
+
+
 @pytest.mark.parametrize("case", ["crafted", "thermal_mixed"])
 def test_lossy_kernel_agrees_with_general_and_oracle(monkeypatch, case):
     """Electrons with radiative losses run mcs_k_transport_lossy: the loss of every pass (particle_loop.jl:302-326) and the
