@@ -323,6 +323,16 @@ int mcs_thermo_calcs(mcs_ctx* ctx, const mcs_consumer_in* in, double* P_par, dou
 int mcs_photon_synch(mcs_ctx* ctx, const double* dNdp_pf, const double* mom_edge_cgs, double mc, int n_photon, double emin_mev,
                      double bins_per_dec, double* energy_erg, double* emis);
 
+/* The pion-decay fold of src/photon_pion_decay.jl:40-183 -> src/pion_kafexhiu.jl:37-245 (Kafexhiu et al. 2014, src/KATV2014.jl) over the
+ * plasma-frame dN/dp of a nucleus species (aa >= 1; frame 2 of mcs_dndp_cr; the thermal histogram of get_normalized_dNdp is empty, quirk C4),
+ * for every grid zone.  dNdp_pf: host [n_grid][nmom+2]; mom_edge_cgs: host [nmom+2]; mc, aa of the species; target_density: host [n_grid]
+ * = n0[1] gam0 beta0 / sqrt(gam_sf^2 - 1) (photon_pion_decay.jl:62-63); scaling: the heavy-nuclei factor of pion_kafexhiu.jl:60-65; i_data:
+ * 1 GEANT 4 (what the reference hard-wires), 2 PYTHIA 8, 3 SIBYLL 2.1, 4 QGSJET-I; photon energies E_j = emin_mev * 10^(j / bins_per_dec)
+ * (photon_calcs.jl:15-16,49: 1 MeV, 10 per decade, 120 bins).  Outputs (host): energy_erg[n_photon] (may be NULL), emis[n_grid][n_photon] =
+ * dP/d(ln E) in erg/s per zone, floor 1e-99.  Dead code in the reference, followed as specification (include/mcs_pion.h: P1-P3). */
+int mcs_photon_pion(mcs_ctx* ctx, const double* dNdp_pf, const double* mom_edge_cgs, double mc, double aa, const double* target_density, double scaling,
+                    int i_data, int n_photon, double emin_mev, double bins_per_dec, double* energy_erg, double* emis);
+
 /* get_dNdp_2D (src/particle_counter.jl:343-627, called at src/ion_finalize.jl:50-59) on the resident psd / therm_sf / num_crossings:
  * d2N/dp dcos of every zone, normalised to the zone population, rebinned by cell centres into the frame that moves with
  * (gam_x, beta_x) against the shock frame -- the ISM frame for (gam0, beta0), the only frame the function returns (m = 2, :538).

@@ -184,7 +184,7 @@ def photon_synch(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: flo
     src/synch_emission.jl over the plasma-frame dN/dp (frame 2 of get_dNdp_cr; the thermal part is empty, quirk C4), on the
     device (K5), then photon_synch's conversion to fluxes at Earth (src/photon_synch.jl:74-108) with the luminosity distance
     of photon_calcs.jl:40.  The photon stack is dead code in the reference: followed as
-    specification.  Inverse Compton: `photon_ic` below; pion decay concerns nuclei and is not built."""
+    specification.  Inverse Compton: `photon_ic` below; pion decay (nuclei): `photon_pion`."""
     P = prob.params
     sp = prob.cfg.species[i_ion - 1]
     if sp.aa >= 1:
@@ -282,6 +282,52 @@ def photon_ic(prob, backend, i_ion: int, jet_dist_kpc: float = 1.0e6, redshift: 
     pflux = np.where(eflux_MeV <= 1.0e-99, 1.0e-99, eflux_MeV / E_MeV[None, :])
     ic_sum = 1.0e-99 + np.where(emis > 1.0e-99, emis / E_erg[None, :], 0.0)
     return PhotonIC(E_MeV, emis, eflux_MeV, pflux, ic_sum, d2n)
+
+
+# ---- pion decay (src/photon_calcs.jl:66-88 -> src/photon_pion_decay.jl -> src/pion_kafexhiu.jl) ------------------------------------
+PHOTON_PION_E_MIN_MEV = 1.0           # photon_calcs.jl:15
+
+
+@dataclasses.dataclass
+class PhotonPion:
+    """What `photon_pion_decay` computes per grid zone (src/photon_pion_decay.jl:40-183) -- it writes it to photon_pion_decay_grid.dat."""
+    energy_MeV: np.ndarray         # [n_photon]
+    emis_erg_s: np.ndarray         # [n_grid][n_photon]  dP/d(ln E) emitted by the zone (pion_kafexhiu), floor 1e-99
+    energy_flux: np.ndarray        # [n_grid][n_photon]  emis / (4 pi d_lum^2): erg / (cm^2 s) per d(ln E) at Earth, floor 1e-99
+    photon_flux: np.ndarray        # [n_grid][n_photon]  energy_flux / E, floor 1e-99
+    pion_photon_sum: np.ndarray    # [n_grid][n_photon]  this species' term of the array get_summed_emission reads (:118-125)
+    n_pion_specs: int              # nuclei species of the run (:69)
+
+
+def pion_scaling_factor(cfg, aa: float) -> float:
+    """Baring et al. (1999) eq. 26 summed over the target nuclei (src/pion_kafexhiu.jl:60-65)."""
+    n1 = cfg.species[0].density
+    return float(sum((aa ** 0.375 + sp.aa ** 0.375 - 1) ** 2 * sp.density / n1 for sp in cfg.species if sp.aa >= 1))
+
+
+def photon_pion(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: float = 1.0e6, redshift: float = 0.0, i_data: int = 1) -> PhotonPion:
+    """The pion-decay branch of `photon_calcs` (src/photon_calcs.jl:66-88) for a nucleus species: per zone, the fold of
+    src/pion_kafexhiu.jl (Kafexhiu et al. 2014) over the plasma-frame dN/dp (frame 2 of get_dNdp_cr; the thermal histogram is empty,
+    quirk C4) against the zone's thermal protons at rest, on the device (K7), then photon_pion_decay's conversion to fluxes at Earth
+    (src/photon_pion_decay.jl:112-125).  Dead code in the reference, followed as specification (include/mcs_pion.h: P1-P3)."""
+    P, cfg = prob.params, prob.cfg
+    sp = cfg.species[i_ion - 1]
+    if sp.aa < 1:
+        raise ValueError("photon_pion: pion-decay emission is computed for nuclei (aa >= 1)")
+    tabs = consumer_tables(prob, i_ion)
+    n = P.n_grid
+    with np.errstate(divide="ignore", invalid="ignore"):
+        target = cfg.species[0].density * (P.gam0 * P.beta0) / np.sqrt(np.asarray(prob.gam_sf)[1:n + 1] ** 2 - 1)      # :62-63
+    n_photon = int(math.log10(PHOTON_E_MAX_MEV / PHOTON_PION_E_MIN_MEV) * PHOTON_BINS_PER_DEC)                   # photon_calcs.jl:49
+    E_erg, emis = backend.photon_pion(ion_fin.dNdp_cr[1], tabs.mom_edge_cgs, tabs.mc, sp.aa, np.ascontiguousarray(target),
+                                      pion_scaling_factor(cfg, sp.aa), n_photon, PHOTON_PION_E_MIN_MEV, PHOTON_BINS_PER_DEC, i_data)
+    dist_lum = jet_dist_kpc * (1 + redshift) * KPC_CM
+    eflux = emis / (4 * math.pi * dist_lum ** 2)
+    lit = eflux >= 1.0e-99
+    eflux = np.where(lit, eflux, 1.0e-99)
+    psum = np.where(lit, eflux / E_erg[None, :], 0.0)
+    pflux = np.where(eflux <= 1.0e-99, 1.0e-99, eflux / E_erg[None, :])
+    return PhotonPion(E_erg / MEV_ERG, emis, eflux, pflux, psum, sum(1 for s in cfg.species if s.aa >= 1))
 
 
 def _takes_download(backend) -> bool:

@@ -47,6 +47,8 @@ hipError_t mcs_launch_dndp_2d(const mcs_params* P, const double* psd, const doub
                               double rest_energy, double n0, int therm_from_hist, double gam_x, double beta_x, double* scratch, double* ef, hipStream_t st);
 hipError_t mcs_launch_photon_ic(const double* ef, const double* p_edge, const double* field, int n_grid, int NM, int NT, int j_max, int n_nu, int n_photon,
                                 double log_min_rm, double bins_per_dec, double mc_e, double beam_area, double* out, hipStream_t st);
+hipError_t mcs_launch_photon_pion(const double* dndp_pf, const double* p_edge, const double* target, int n_grid, int NM, int n_photon,
+                                  double log_emin_erg, double bins_per_dec, double mc, double aa, double scaling, int i_data, double* out, hipStream_t st);
 hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
                                    double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st);
 hipError_t mcs_launch_thermo(const mcs_params* P, const double* psd, const double* therm_pf, const unsigned long long* num_crossings,
@@ -1131,6 +1133,32 @@ int mcs_photon_synch(mcs_ctx* c, const double* dNdp_pf, const double* mom_edge_c
   HIPCHK(hipMemcpyAsync(d_in + (size_t)ng * NM, mom_edge_cgs, sizeof(double) * NM, hipMemcpyHostToDevice, c->stream));
   const double log_emin = std::log10(emin_mev * MCS_MEV_ERG_);
   HIPCHK(mcs_launch_photon_synch(d_in, d_in + (size_t)ng * NM, c->tb.btot, ng, NM, n_photon, log_emin, bins_per_dec, mc, d_out, c->stream));
+  HIPCHK(hipMemcpyAsync(emis, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (energy_erg) for (int j = 0; j < n_photon; ++j) energy_erg[j] = std::pow(10.0, log_emin + j * (1.0 / bins_per_dec));
+  return 0;
+}
+
+// The pion-decay fold (include/mcs_pion.h) over the plasma-frame dN/dp of a nucleus species.
+int mcs_photon_pion(mcs_ctx* c, const double* dNdp_pf, const double* mom_edge_cgs, double mc, double aa, const double* target_density, double scaling,
+                    int i_data, int n_photon, double emin_mev, double bins_per_dec, double* energy_erg, double* emis) {
+  HIPCHK(hipSetDevice(c ? c->device : 0));
+  if (!c || !dNdp_pf || !mom_edge_cgs || !target_density || !emis) return fail("mcs_photon_pion: null argument");
+  if (!c->have_grid) return fail("mcs_photon_pion: grid not set");
+  if (n_photon < 1 || n_photon > 4096 || !(emin_mev > 0) || !(bins_per_dec > 0) || !(mc > 0) || !(aa >= 1) || !(scaling >= 0))
+    return fail("mcs_photon_pion: bad arguments");
+  if (i_data < 1 || i_data > 4) return fail("mcs_photon_pion: i_data must be between 1 and 4");        // pion_kafexhiu.jl:81-88
+  const int NM = c->P.num_psd_mom_bins + 2, ng = c->P.n_grid;
+  if (NM > 208) return fail("mcs_photon_pion: too many momentum bins");
+  const size_t n_in = (size_t)ng * NM + NM + ng, n_out = (size_t)ng * n_photon;
+  if (ensure_stage(c, (long long)(n_in + n_out) + 4)) return 1;
+  double* d_in = c->d_stage; double* d_out = c->d_stage + n_in;
+  HIPCHK(hipMemcpyAsync(d_in, dNdp_pf, sizeof(double) * (size_t)ng * NM, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_in + (size_t)ng * NM, mom_edge_cgs, sizeof(double) * NM, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_in + (size_t)ng * NM + NM, target_density, sizeof(double) * ng, hipMemcpyHostToDevice, c->stream));
+  const double log_emin = std::log10(emin_mev * MCS_MEV_ERG_);
+  HIPCHK(mcs_launch_photon_pion(d_in, d_in + (size_t)ng * NM, d_in + (size_t)ng * NM + NM, ng, NM, n_photon, log_emin, bins_per_dec, mc, aa, scaling,
+                                i_data, d_out, c->stream));
   HIPCHK(hipMemcpyAsync(emis, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (energy_erg) for (int j = 0; j < n_photon; ++j) energy_erg[j] = std::pow(10.0, log_emin + j * (1.0 / bins_per_dec));

@@ -16,6 +16,7 @@
 #include "../../include/mcs_math.h"
 #include "../../include/mcs_synch.h"
 #include "../../include/mcs_ic.h"
+#include "../../include/mcs_pion.h"
 
 #pragma clang fp contract(off)
 
@@ -483,6 +484,39 @@ __global__ void __launch_bounds__(256) mcs_k_photon_synch(const double* __restri
 extern "C" hipError_t mcs_launch_photon_synch(const double* dndp_pf, const double* p_edge, const double* btot, int n_grid, int NM, int n_photon,
                                               double log_emin_erg, double bins_per_dec, double mc, double* out, hipStream_t st) {
   hipLaunchKernelGGL(mcs_k_photon_synch, dim3((unsigned)n_grid), dim3(256), 0, st, dndp_pf, p_edge, btot, NM, n_photon, log_emin_erg, bins_per_dec, mc, out);
+  return hipGetLastError();
+}
+
+// ---- K7: the pion-decay fold of the photon post-processing (include/mcs_pion.h) --------------------------------
+// One workgroup per grid zone.  First one thread per momentum bin prepares what does not depend on the photon energy (T_p, E_gamma^max,
+// A_max, target density x count x speed: pion_kafexhiu.jl:171-193); then one thread per photon energy walks the bins in the reference's
+// order, so a spectrum is the same sum in the same order on the CPU twin.  O(n_grid x n_photon x nmom) evaluations of F(T_p, E).
+__global__ void __launch_bounds__(256) mcs_k_photon_pion(const double* __restrict__ dndp_pf /*[n_grid][NM]*/, const double* __restrict__ p_edge /*[NM]*/,
+                                                        const double* __restrict__ target /*[n_grid]*/, int NM, int n_photon, double log_emin_erg,
+                                                        double bins_per_dec, double mc, double aa, double scaling, int i_data,
+                                                        double* __restrict__ out /*[n_grid][n_photon]*/) {
+  __shared__ double s_pref[KC_MAXB], s_T[KC_MAXB], s_E[KC_MAXB], s_A[KC_MAXB];
+  const int zone = blockIdx.x;
+  const double n_t = target[zone];
+  for (int i = threadIdx.x; i < NM - 1; i += blockDim.x) {
+    const double d = dndp_pf[(long long)zone * NM + i];
+    const double lo = p_edge[i], hi = p_edge[i + 1];
+    const double cnt = d <= 1.0e-99 ? 1.0e-99 : d * (hi - lo);                                   // photon_pion_decay.jl:86-92
+    double T = 0, v = 0, E = 1, A = 0;
+    const int ok = mcs_pion_bin(cnt, lo, hi, mc, aa, i_data, &T, &v, &E, &A);
+    s_pref[i] = ok ? n_t * cnt * v : 0.0; s_T[i] = T; s_E[i] = E; s_A[i] = A;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n_photon; j += blockDim.x) {
+    const double e = pow(10.0, log_emin_erg + j * (1.0 / bins_per_dec));
+    out[(long long)zone * n_photon + j] = mcs_pion_fold_one(s_pref, s_T, s_E, s_A, NM - 1, i_data, e, scaling);
+  }
+}
+extern "C" hipError_t mcs_launch_photon_pion(const double* dndp_pf, const double* p_edge, const double* target, int n_grid, int NM, int n_photon,
+                                             double log_emin_erg, double bins_per_dec, double mc, double aa, double scaling, int i_data, double* out,
+                                             hipStream_t st) {
+  hipLaunchKernelGGL(mcs_k_photon_pion, dim3((unsigned)n_grid), dim3(256), 0, st, dndp_pf, p_edge, target, NM, n_photon, log_emin_erg, bins_per_dec, mc,
+                     aa, scaling, i_data, out);
   return hipGetLastError();
 }
 

@@ -312,6 +312,18 @@ class HipBackend:
         self._chk(self.lib.mcs_photon_synch(self.h, _dp(d), _dp(pe), float(mc), int(n_photon), float(emin_mev), float(bins_per_dec), _dp(E), _dp(out)))
         return E, out
 
+    def photon_pion(self, dndp_pf, mom_edge_cgs, mc, aa, target_density, scaling, n_photon, emin_mev, bins_per_dec, i_data=1):
+        """K7: pion-decay emission dP/d(ln E) [erg/s] per zone from the plasma-frame dN/dp of a nucleus species -> (E_erg[n_photon],
+        emis[n_grid][n_photon])."""
+        d = np.ascontiguousarray(dndp_pf, dtype=np.float64); pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        td = np.ascontiguousarray(target_density, dtype=np.float64)
+        assert d.shape == (self.P.n_grid, self.P.num_psd_mom_bins + 2) and pe.shape == (self.P.num_psd_mom_bins + 2,)
+        assert td.shape == (self.P.n_grid,)
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.mcs_photon_pion(self.h, _dp(d), _dp(pe), float(mc), float(aa), _dp(td), float(scaling), int(i_data), int(n_photon),
+                                           float(emin_mev), float(bins_per_dec), _dp(E), _dp(out)))
+        return E, out
+
     def dndp_2d(self, tabs, gam_x, beta_x, download=True):
         """K6: get_dNdp_2D on the resident histograms -> d2N/dp dcos [n_grid][ntht+2][nmom+2] in the frame (gam_x, beta_x); the array
         stays on the device for photon_ic (download=False: nothing crosses PCIe)."""

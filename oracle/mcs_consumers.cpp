@@ -32,6 +32,7 @@
 #include "../include/mcs.h"
 #include "../include/mcs_synch.h"
 #include "../include/mcs_ic.h"
+#include "../include/mcs_pion.h"
 
 #include <cmath>
 #include <cstdint>
@@ -334,6 +335,38 @@ int orc_photon_synch(const mcs_params* Pp, const double* dNdp_pf, const double* 
   return 0;
 }
 double orc_synch_F(double x) { return mcs_synch_F(x); }
+
+// The pion-decay fold (src/photon_pion_decay.jl:40-183 -> src/pion_kafexhiu.jl:37-245), CPU twin of mcs_photon_pion: the same header
+// (include/mcs_pion.h), glibc math.
+int orc_photon_pion(const mcs_params* Pp, const double* dNdp_pf, const double* mom_edge_cgs, double mc, double aa, const double* target_density,
+                    double scaling, int i_data, int n_photon, double emin_mev, double bins_per_dec, double* energy_erg, double* emis) {
+  const int NM = Pp->num_psd_mom_bins + 2, ng = Pp->n_grid;
+  if (i_data < 1 || i_data > 4 || NM > 4096) return 1;
+  const double log_emin = std::log10(emin_mev * MCS_MEV_ERG);
+  std::vector<double> pref(NM), T(NM), Em(NM), A(NM);
+  for (int zone = 0; zone < ng; ++zone) {
+    for (int i = 0; i < NM - 1; ++i) {
+      const double d = dNdp_pf[(size_t)zone * NM + i], lo = mom_edge_cgs[i], hi = mom_edge_cgs[i + 1];
+      const double cnt = d <= 1.0e-99 ? 1.0e-99 : d * (hi - lo);
+      double t = 0, v = 0, e = 1, a = 0;
+      const int ok = mcs_pion_bin(cnt, lo, hi, mc, aa, i_data, &t, &v, &e, &a);
+      pref[i] = ok ? target_density[zone] * cnt * v : 0.0; T[i] = t; Em[i] = e; A[i] = a;
+    }
+    for (int j = 0; j < n_photon; ++j) {
+      const double e = std::pow(10.0, log_emin + j * (1.0 / bins_per_dec));
+      if (zone == 0 && energy_erg) energy_erg[j] = e;
+      emis[(size_t)zone * n_photon + j] = mcs_pion_fold_one(pref.data(), T.data(), Em.data(), A.data(), NM - 1, i_data, e, scaling);
+    }
+  }
+  return 0;
+}
+// the three functions of src/KATV2014.jl, for the tests' independent restatement
+double orc_pion_sigma_pi(double Tp, int i_data) { return mcs_pion_sigma_pi(Tp, i_data, 2 * MCS_PION_MPC2 * (Tp + 2 * MCS_PION_MPC2)); }
+void orc_pion_amax(double Tp, int i_data, double* Egmax, double* Amax) {
+  const double s = 2 * MCS_PION_MPC2 * (Tp + 2 * MCS_PION_MPC2);
+  mcs_pion_amax(Tp, i_data, s, mcs_pion_sigma_pi(Tp, i_data, s), Egmax, Amax);
+}
+double orc_pion_F(double Tp, double Eg, int i_data, double Egmax) { return mcs_pion_F(Tp, Eg, i_data, Egmax); }
 
 // get_dNdp_2D (src/particle_counter.jl:343-627), CPU twin of mcs_dndp_2d: d2N/dp dcos per zone in the shock frame from the thermal
 // crossings (therm_sf histogram: A9) and the psd, normalised to the zone population, rebinned by cell centres into the frame moving

@@ -77,6 +77,10 @@ def load(math: str = "det", capi=None):
         sig["orc_dndp_2d"] = (i32, [par_p, dp, i64p, cin_p, dbl, dbl, dp])
         sig["orc_photon_ic"] = (i32, [par_p, dp, dp, dbl, i32, i32, dp, dp, i32, dbl, dbl, dbl, dp, dp])
         sig["orc_synch_F"] = (dbl, [dbl])
+        sig["orc_photon_pion"] = (i32, [par_p, dp, dp, dbl, dbl, dp, dbl, i32, i32, dbl, dbl, dp, dp])
+        sig["orc_pion_sigma_pi"] = (dbl, [dbl, i32])
+        sig["orc_pion_amax"] = (None, [dbl, i32, dp, dp])
+        sig["orc_pion_F"] = (dbl, [dbl, dbl, i32, dbl])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -275,6 +279,15 @@ class OracleBackend:
         E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
         self._chk(self.lib.orc_photon_synch(ct.byref(self.P), _dp(d), _dp(pe), _dp(bt), float(mc), int(n_photon), float(emin_mev),
                                             float(bins_per_dec), _dp(E), _dp(out)))
+        return E, out
+
+    def photon_pion(self, dndp_pf, mom_edge_cgs, mc, aa, target_density, scaling, n_photon, emin_mev, bins_per_dec, i_data=1):
+        d = np.ascontiguousarray(dndp_pf, dtype=np.float64); pe = np.ascontiguousarray(mom_edge_cgs, dtype=np.float64)
+        td = np.ascontiguousarray(target_density, dtype=np.float64)
+        assert d.shape == (self.P.n_grid, self.P.num_psd_mom_bins + 2) and td.shape == (self.P.n_grid,)
+        E = np.zeros(n_photon); out = np.zeros((self.P.n_grid, n_photon))
+        self._chk(self.lib.orc_photon_pion(ct.byref(self.P), _dp(d), _dp(pe), float(mc), float(aa), _dp(td), float(scaling), int(i_data), int(n_photon),
+                                           float(emin_mev), float(bins_per_dec), _dp(E), _dp(out)))
         return E, out
 
     # -- consumers of the tallies (oracle/mcs_consumers.cpp)
