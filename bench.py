@@ -105,6 +105,26 @@ def overlapped_leg(mcs, hip_backend, prob, be0, local, args):
             "steps": n, "note": "independent iterations (fixed shock profile) sharing the GPU; not the headline value"}
 
 
+def pipelined_leg(mcs, prob, be, args, first_iter, sm):
+    """NOT the headline: the same `steps` iterations with the pcuts pipelined (mcs_run_pcuts_pipelined: a pcut's long histories finish
+    beside the next pcut on CU-masked streams; the next population is ordered not-long before long, the oracle likewise --
+    tests/test_pipelined_pcuts.py), timed like the main region.  Reported beside it because the per-launch roofline of the headline has
+    no meaning for launches that share the chip."""
+    import torch
+    kw = dict(smoothing=sm, species_tallies=args.species_tallies, long_draws=args.long_draws)
+    mcs.driver.run(prob, be, n_itrs=1, first_iter=first_iter, **kw)                        # warm (second stream, buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = mcs.driver.run(prob, be, n_itrs=args.steps, first_iter=first_iter + 1, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = sum(s for _, _, s in res.local_steps)
+    return {"long_draws": args.long_draws, "long_imult_max": int(os.environ.get("MCS_LONG_IMULT_MAX", "8")), "value": steps / dt,
+            "unit": "particle-scatter steps/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+            "main_launch_ms_per_step": sum(s.kernel_ms for s in res.stats) / args.steps,
+            "note": "one iteration after the other, every pcut's long histories beside the next pcut; not the headline value"}
+
+
 def workload_label(args):
     """What actually ran, built from the arguments: every kept bench line names its own workload."""
     n = args.particles
@@ -160,6 +180,8 @@ def main():
                     help="what the host fetches at every species end: the 0.8 MB it computes with (light) or the whole 61 MB buffer (full)")
     ap.add_argument("--overlap", type=int, default=2,
                     help="extra leg, reported beside `value` and never in it: this many independent iterations in flight (driver.run_overlapped); 1 = skip")
+    ap.add_argument("--long-draws", type=int, default=8192,
+                    help="extra leg at N=1 (not the headline): the pcuts pipelined, long histories = this many random draws (0: skip)")
     ap.add_argument("--smooth", action="store_true", help="replace the shock profile after every iteration (smooth_grid_par): config[2]'s loop")
     ap.add_argument("--mixed", action="store_true", help="BASELINE config[4]'s species mix: protons + He + electrons, radiative losses, ion -> electron energy transfer (--particles per species)")
     ap.add_argument("--fp32", action="store_true", help="the fp32-state variant of the transport kernel (config[4]); tallies stay fp64")
@@ -201,6 +223,10 @@ def main():
     # (room in the per-iteration tallies for the iterations of the extra overlapped leg, which carry on the numbering)
     overlap_leg = world == 1 and not force_comm and args.overlap > 1 and not args.smooth and not args.mixed and not args.fp32
     n_extra = (2 * args.overlap + args.steps) if overlap_leg else 0
+    pipe_leg = world == 1 and not force_comm and args.long_draws > 0 and not args.mixed and not args.fp32
+    pipe_first = n_itrs + n_extra + 1
+    if pipe_leg:
+        n_extra += 1 + args.steps
     kw = {}
     if args.mixed:
         me_mp = mcs.constants.ME / mcs.constants.MP
@@ -312,6 +338,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mcs, args.cpu_sample, n_sample_1t=args.cpu_sample_1t)
         if overlap_leg:
             out["overlapped_iterations"] = overlapped_leg(mcs, hip_backend, prob, be, local, args)
+        if pipe_leg:
+            out["pipelined_pcuts"] = pipelined_leg(mcs, prob, be, args, pipe_first, sm)
         if args.mixed and world == 1:
             # the photon leg of config[4] ("inverse-Compton/synch photon tallies"): ion_finalize's photon_calcs for the electron
             # species on the histograms the last iteration left on the device (K4 dN/dp, K5 synchrotron, K6 get_dNdp_2D + IC).

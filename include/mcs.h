@@ -275,6 +275,19 @@ int mcs_split_import(mcs_ctx* ctx, int64_t n_parents, int64_t cap, const double*
 int mcs_run_pcut_host(mcs_ctx* ctx, int i_pcut, int64_t n_pts_use, int64_t i_prt_offset,
                       const mcs_soa* in, mcs_soa* saved_out, uint8_t* l_save, int64_t* n_saved);
 
+/* A species' pcuts with the long histories of every pcut finishing BESIDE the next pcut, on a second stream (the loop at
+ * src/main_loops.jl:184-292 with pcut_finalize / new_pcut, src/cuts.jl:34-124, as mcs_run_pcuts_fused).  A particle is LONG in a pcut when
+ * its history there took at least long_draws random draws; the next population is the children of the saved particles that are not
+ * long, in index order, followed by the children of the saved long ones, in index order (the reference's order for long_draws =
+ * infinity; the index keys a child's random stream, so the order is part of the result -- the oracle orders the same way:
+ * orc_set_long_draws).  long_imult_max > 0: long histories are told apart only in the first pcut and in pcuts whose predecessor split by
+ * at most that factor (elsewhere the pcut runs as one launch, in the reference's order): where few particles are saved and each is split a
+ * hundredfold, i_mult hangs on the last long history.  n_target[k]: the target population after pcut first + k.  Outputs (host, length last - first + 1): n_use,
+ * n_saved, i_mult per pcut, the main launch's kernel time; strag_out (or NULL, length 2 per pcut): particles exported, and 1 where
+ * i_mult had to wait for them.  One rank with global indices 0, 1, 2, ...; fp64 state; not with sliced launches. */
+int mcs_run_pcuts_pipelined(mcs_ctx* ctx, int i_pcut_first, int i_pcut_last, const int64_t* n_target, int64_t long_draws, int64_t long_imult_max,
+                            int64_t* n_use_out, int64_t* n_saved_out, int64_t* i_mult_out, double* kernel_ms_out, int64_t* strag_out);
+
 /* ---- tallies ------------------------------------------------------------ */
 int mcs_read_tallies(mcs_ctx* ctx, double* host_f64 /*layout.total*/, int64_t* host_i64 /*mcs_i64_total*/);
 /* A slice of the fp64 buffer, words [first, first + count) of the layout, into host_f64[0 .. count) (+ all int64 tallies

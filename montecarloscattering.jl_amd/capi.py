@@ -244,6 +244,7 @@ def load_library() -> ct.CDLL:
         "mcs_thermo_calcs": (i32, [vp, ct.POINTER(McsConsumerIn), c_double_p, c_double_p, c_double_p]),
         "mcs_photon_synch": (i32, [vp, c_double_p, c_double_p, dbl, i32, dbl, dbl, c_double_p, c_double_p]),
         "mcs_run_pcuts_fused": (i32, [vp, i32, i32, c_int64_p, c_int64_p, c_int64_p, c_int64_p, c_double_p]),
+        "mcs_run_pcuts_pipelined": (i32, [vp, i32, i32, c_int64_p, ct.c_int64, ct.c_int64, c_int64_p, c_int64_p, c_int64_p, c_double_p, c_int64_p]),
         "mcs_dndp_2d": (i32, [vp, ct.POINTER(McsConsumerIn), dbl, dbl, c_double_p]),
         "mcs_photon_ic": (i32, [vp, c_double_p, dbl, i32, i32, c_double_p, c_double_p, i32, dbl, dbl, dbl, c_double_p, c_double_p]),
         "mcs_photon_pion": (i32, [vp, c_double_p, c_double_p, dbl, dbl, c_double_p, dbl, i32, i32, dbl, dbl, c_double_p, c_double_p]),
@@ -265,5 +266,5 @@ EXPORTED_SYMBOLS = [
     "mcs_get_layout", "mcs_dndp_cr", "mcs_thermo_calcs",
     "mcs_run_pcut_strided", "mcs_run_pcut_indexed", "mcs_saved_gidx", "mcs_init_pop_binned_strided", "mcs_saved_export", "mcs_split_import", "mcs_set_debug_finals", "mcs_set_retro_cap",
     "mcs_set_tail_slicing", "mcs_last_launches", "mcs_last_kernel", "mcs_write_tallies_part", "mcs_photon_synch",
-    "mcs_dndp_2d", "mcs_photon_ic", "mcs_run_pcuts_fused", "mcs_photon_pion",
+    "mcs_dndp_2d", "mcs_photon_ic", "mcs_run_pcuts_fused", "mcs_photon_pion", "mcs_run_pcuts_pipelined",
 ]

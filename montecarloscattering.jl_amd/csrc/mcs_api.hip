@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 extern "C" {
 size_t mcs_transport_smem_bytes(int n_grid, int n_tcuts);
@@ -27,6 +28,11 @@ hipError_t mcs_launch_transport_f32(const KArgs* a_dev, int kind, int blocks, in
 hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
                               unsigned long long* total_dev, long long* src, hipStream_t st);
 hipError_t mcs_launch_split(DevPop sv, DevPop out, const long long* src, long long n_new, long long i_mult, hipStream_t st);
+hipError_t mcs_launch_compact_match(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                    unsigned long long* total_dev, long long* src, unsigned int match, hipStream_t st);
+hipError_t mcs_launch_late_split(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                 unsigned long long* total_dev, long long* src, PcutDev* pd, long long i_mult, long long n_main_next, DevPop sv,
+                                 DevPop out_at_main_end, int split_blocks, hipStream_t st);
 hipError_t mcs_launch_saved_export(DevPop sv, const long long* src, long long n_saved, long long cap, long long first,
                                    long long stride, const long long* gin, long long* gidx, double* f64, uint32_t* meta,
                                    hipStream_t st);
@@ -137,6 +143,21 @@ struct mcs_ctx {
   // device, one event pair per pcut
   KArgs* h_fargs = nullptr; KArgs* d_fargs = nullptr; PcutDev* d_pd = nullptr; PcutDev* h_pd = nullptr; int fused_cap = 0;
   std::vector<hipEvent_t> f_ev;
+  // pipelined pcut loop (mcs_run_pcuts_pipelined): the side stream on which a pcut's long histories finish while the next pcut runs,
+  // the second set of saved arrays / status bytes (pcut p's are still written while pcut p + 1 runs), the late group's scan scratch,
+  // per-launch counters (device, and pinned for the one read-back per pcut), three launch-constant slots, the late group's sizes
+  hipStream_t pp_s2 = nullptr; hipEvent_t pp_reset = nullptr;
+  // ... and, when the runtime grants them, two streams with complementary CU masks: the side stream's waves then have their SIMDs to
+  // themselves (beside a wave of the main launch on the same SIMD a long history advances at half the speed -- the kernel is issue-bound
+  // -- and the side chain, not the main launch, ends the pcut); a pcut with side work runs its main launch on the masked main stream
+  hipStream_t pp_s1m = nullptr, pp_s2m = nullptr; int pp_side_cus = 12;      // MCS_PIPE_SIDE_CUS=<n> (0: no masks)
+  PopBuf pp_sav2; uint8_t* pp_lsave2 = nullptr; long long pp_cap = 0;
+  unsigned int* pp_bcounts = nullptr; unsigned long long* pp_boffs = nullptr; long long* pp_src = nullptr;
+  unsigned long long* pp_dpc = nullptr; unsigned long long* pp_hpc = nullptr;
+  KArgs* pp_hargs = nullptr; KArgs* pp_dargs = nullptr; PcutDev* pp_dpdl = nullptr; PcutDev* pp_hpdl = nullptr;
+  int pp_side_waves = 0;       // MCS_PIPE_SIDE_WAVES=<n>: waves the resumed long histories are spread over (0: one per SIMD of the chip)
+  int pp_side_max = 64;        // MCS_PIPE_SIDE_MAX=<n>: workgroups (of 2 per CU) the main launch leaves free for them at most
+  int pp_waits_last = 0;       // pcuts of the last pipelined run whose i_mult had to wait for the long histories
   bool force_general = false;  // MCS_FORCE_GENERAL=1: always the general kernel (tests compare the two)
   int k1_ws = 2;               // the wave-specialised kernels (mcs_transport_ws.inc), where they apply: MCS_K1_WS=1 always, =0 never, default (2)
                                // for populations of at least ws_auto_min particles -- measured level with transport_body at 4e6 particles, 3.8 %
@@ -308,6 +329,9 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_F32_BLOCKS"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 8) c->f32_blocks_per_cu = std::atoi(e); }
   { const char* e = std::getenv("MCS_TAIL_BUDGET"); if (e && std::atoi(e) >= 0) c->tail_budget = std::atoi(e); }
   { const char* e = std::getenv("MCS_CLAIM_MAX"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->claim_max_first = std::atoi(e); }
+  { const char* e = std::getenv("MCS_PIPE_SIDE_WAVES"); if (e && std::atoi(e) >= 1) c->pp_side_waves = std::atoi(e); }
+  { const char* e = std::getenv("MCS_PIPE_SIDE_CUS"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 128) c->pp_side_cus = std::atoi(e); }
+  { const char* e = std::getenv("MCS_PIPE_SIDE_MAX"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 256) c->pp_side_max = std::atoi(e); }
   { const char* e = std::getenv("MCS_REFILL_MIN"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 48) c->refill_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_DEFER_K"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 40) c->defer_k = std::atoi(e); }
   c->P = *p;
@@ -363,6 +387,15 @@ int mcs_destroy(mcs_ctx* c) {
   if (c->h_pd) (void)hipHostFree(c->h_pd);
   if (c->d_fargs) (void)hipFree(c->d_fargs);
   if (c->d_pd) (void)hipFree(c->d_pd);
+  pop_free(c->pp_sav2);
+  { void* pq[] = {c->pp_lsave2, c->pp_bcounts, c->pp_boffs, c->pp_src, c->pp_dpc, c->pp_dargs, c->pp_dpdl}; for (void* q : pq) if (q) (void)hipFree(q); }
+  if (c->pp_hpc) (void)hipHostFree(c->pp_hpc);
+  if (c->pp_hargs) (void)hipHostFree(c->pp_hargs);
+  if (c->pp_hpdl) (void)hipHostFree(c->pp_hpdl);
+  if (c->pp_reset) (void)hipEventDestroy(c->pp_reset);
+  if (c->pp_s2) (void)hipStreamDestroy(c->pp_s2);
+  if (c->pp_s1m) (void)hipStreamDestroy(c->pp_s1m);
+  if (c->pp_s2m) (void)hipStreamDestroy(c->pp_s2m);
   for (auto e : c->f_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -928,6 +961,290 @@ int mcs_run_pcuts_fused(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const int
   c->n_run_last = -1; c->n_saved_last = 0;
   c->last_ms = ms_sum; c->tail_rounds_last = npc;
   c->kernel_last = c->P.state_fp32 ? (c->f32_exact ? 9 : (c->f32_loop ? 4 : (kind == 2 ? 5 : 3))) : kind;
+  return 0;
+}
+
+// ---- A species' pcuts with the long histories of pcut p finishing BESIDE pcut p + 1 (DESIGN.md "Pipelined pcuts").
+// A launch waits for its longest histories -- 10^4 passes of single particles while the chip idles (40 % of an iteration at 10^6
+// particles).  What stands in the way of starting the next pcut is the ORDER of its population: child o of the split is a copy of
+// saved particle o / i_mult in index order (src/cuts.jl:66-92), and the index keys the child's random stream -- one unresolved
+// particle leaves every index behind it open.  Here the order is made independent of the schedule: a particle is LONG in a pcut when its
+// history there took at least `long_draws` random draws (a property of its stream alone), and the next population is the children of
+// the saved particles that are not long, in index order, followed by the children of the saved long ones, in index order.  The oracle
+// orders the same way (orc_set_long_draws), so parity stays bit for bit; long_draws is a parameter of the algorithm like the seeds.
+// Per pcut: the main launch (stream) and the late launch (side stream: the children of the previous pcut's saved long particles)
+// export the particles that are still running once they are long and end; both join; the main group is split and the next main
+// launch starts, while on the side stream the exported particles run to their end, the late group is split and the next late launch
+// runs.  i_mult = max(n_target / n_saved, 1) needs the number of long particles that will be saved: it is taken as soon as both
+// bounds give the same quotient, else the pcut waits for them (counted in strag_out).  One rank, global indices 0, 1, 2, ...; fp64 state.
+// Outputs as mcs_run_pcuts_fused; strag_out (or NULL): [2k] particles pcut k exported, [2k + 1] 1 if its i_mult had to wait.
+int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const int64_t* n_target, int64_t long_draws, int64_t long_imult_max,
+                            int64_t* n_use_out, int64_t* n_saved_out, int64_t* i_mult_out, double* kernel_ms_out, int64_t* strag_out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->have_grid || !c->have_cuts) return fail("mcs_run_pcuts_pipelined: grid/cuts not set");
+  if (i_pcut_first < 1 || i_pcut_last > c->tb.n_pcuts || i_pcut_last < i_pcut_first) return fail("mcs_run_pcuts_pipelined: pcut range");
+  if (!n_target || !n_use_out || !n_saved_out || !i_mult_out) return fail("mcs_run_pcuts_pipelined: null argument");
+  if (c->P.state_fp32) return fail("mcs_run_pcuts_pipelined: not for the fp32-state variant");
+  if (c->tail_budget > 0 || c->claim_max_first < 64 || c->blocks > 0) return fail("mcs_run_pcuts_pipelined: not with sliced launches or an explicit launch geometry");
+  if (long_draws < 64 || long_draws > 2000000000LL) return fail("mcs_run_pcuts_pipelined: long_draws out of range (64 .. 2e9)");
+  const int npc = i_pcut_last - i_pcut_first + 1;
+  long long cap_n = c->n;
+  for (int k = 0; k < npc; ++k) { if (n_target[k] < 1) return fail("mcs_run_pcuts_pipelined: n_target < 1"); if (n_target[k] > cap_n) cap_n = n_target[k]; }
+  const long long cap = cap_n + cap_n / 8 + 1024;
+  if (ensure_capacity(c, cap_n)) return 1;
+  if (pop_alloc(c, c->spare, cap)) return 1;
+  if (pop_alloc(c, c->pp_sav2, cap)) return 1;
+  if (c->pp_cap < cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    { void* pq[] = {c->pp_lsave2, c->pp_bcounts, c->pp_boffs, c->pp_src}; for (void* q : pq) if (q) (void)hipFree(q); }
+    const long long nb = (cap + 1023) / 1024;
+    HIPCHK(hipMalloc((void**)&c->pp_lsave2, (size_t)cap));
+    HIPCHK(hipMalloc((void**)&c->pp_bcounts, (size_t)nb * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&c->pp_boffs, (size_t)nb * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&c->pp_src, (size_t)cap * sizeof(long long)));
+    c->pp_cap = cap;
+  }
+  if (!c->pp_s2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->pp_s2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->pp_reset, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void**)&c->pp_dpc, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void**)&c->pp_hpc, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void**)&c->pp_hargs, 3 * sizeof(KArgs)));
+    HIPCHK(hipMalloc((void**)&c->pp_dargs, 3 * sizeof(KArgs)));
+    HIPCHK(hipMalloc((void**)&c->pp_dpdl, 2 * sizeof(PcutDev)));
+    HIPCHK(hipHostMalloc((void**)&c->pp_hpdl, 2 * sizeof(PcutDev)));
+    if (c->pp_side_cus > 0 && c->pp_side_cus < c->n_cu) {
+      const int words = (c->n_cu + 31) / 32;
+      std::vector<uint32_t> m_side((size_t)words, 0u), m_main((size_t)words, 0u);
+      for (int i = 0; i < c->n_cu; ++i) (i < c->pp_side_cus ? m_side : m_main)[(size_t)(i >> 5)] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&c->pp_s1m, (uint32_t)words, m_main.data()) != hipSuccess ||
+          hipExtStreamCreateWithCUMask(&c->pp_s2m, (uint32_t)words, m_side.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->pp_s1m) { (void)hipStreamDestroy(c->pp_s1m); c->pp_s1m = nullptr; }
+        if (c->pp_s2m) { (void)hipStreamDestroy(c->pp_s2m); c->pp_s2m = nullptr; }
+      }
+    }
+  }
+  const int threads = 256;
+  const long long full = (long long)c->n_cu * 2;            // resident workgroups of the fp64 kernels
+  {   // a wave exports at most its 64 lanes, once: room for the main and the late launch of one pcut
+    const long long need_cap = 2 * full * threads;
+    if (need_cap > c->strag_cap) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      for (int b = 0; b < 2; ++b) { if (c->d_strag[b]) (void)hipFree(c->d_strag[b]); c->d_strag[b] = nullptr; }
+      c->strag_cap = need_cap;
+      for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void**)&c->d_strag[b], (size_t)c->strag_cap * MCS_STRAG_WORDS * sizeof(double)));
+    }
+  }
+  // counters: [0] work, [1] n_saved of the main launch | [2] main scan total | [3 + q] particles exported by pcut parity q |
+  // [5] work, [6] n_saved of the resumed long histories | [7] work, [8] n_saved of the late launch | [9] late scan total
+  unsigned long long* const pc = c->pp_dpc;
+  const bool masked = c->pp_s1m && c->pp_s2m;
+  hipStream_t s1 = c->stream;                              // the main stream of the CURRENT pcut: c->stream, or the masked one when the pcut has side work
+  hipStream_t const s2 = masked ? c->pp_s2m : c->pp_s2;    // the side stream
+  hipStream_t const s_alone = masked ? c->stream : c->pp_s2;   // long histories the pcut waits for: the whole chip
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int kind;
+  {
+    KArgs t; fill_kargs(c, t, i_pcut_first, 0, 0, 1, nullptr, 0);
+    int kk = species_kernel_kind(c, t, 0, nullptr);
+    if (kk == 7) kk = 1;
+    kind = kk == 1 ? 11 : 10;          // the sliced form of the PLAIN kernel, else of the general one
+  }
+  PopBuf cur = c->cur, nxt = c->spare;
+  PopBuf savb[2] = {c->sav, c->pp_sav2};
+  uint8_t* lsv[2] = {c->d_lsave, c->pp_lsave2};
+  long long nA = c->n, nL = 0;
+  // long histories are told apart in pcut k only when the pcut before it split by at most long_imult_max (<= 0: always): where few
+  // particles are saved and each is split a hundredfold, i_mult hangs on the last long history and the pcut would wait for them anyway
+  // (a rule on numbers the oracle has too: driver.py applies it to set_long_draws)
+  long long Bk = long_draws;
+  bool side_pending = false;
+  int side_blocks = 0;               // workgroups the side stream's launches of this pcut need resident beside the main launch
+  long long n1_prev = 0, sofar_prev = 0;
+  double ms_sum = 0.0;
+  int n_done = 0;
+  c->pp_waits_last = 0;
+  c->tail_rounds_last = 0;
+  const bool dbg_pipe = std::getenv("MCS_PIPE_DEBUG") != nullptr;
+  for (int k = 0; k < npc; ++k) { n_use_out[k] = 0; n_saved_out[k] = 0; i_mult_out[k] = 1; if (kernel_ms_out) kernel_ms_out[k] = 0.0; if (strag_out) { strag_out[2 * k] = 0; strag_out[2 * k + 1] = 0; } }
+  HIPCHK(hipMemsetAsync(pc, 0, 16 * sizeof(unsigned long long), s1));
+  if (nA > 0) HIPCHK(hipMemsetAsync(lsv[0], 0, (size_t)nA, s1));
+  auto blocks_for = [&](long long n) { const long long want = (n + threads - 1) / threads; return (int)(want < full ? (want > 0 ? want : 1) : full); };
+  // the launch of the exported particles of pcut `i_pcut` (parity q), to their end, on `st`
+  auto launch_resume = [&](int i_pcut, int q, long long n_pop, long long n_x, hipStream_t st, bool alone) -> int {
+    KArgs& a = c->pp_hargs[1];
+    fill_kargs(c, a, i_pcut, n_pop, 0, 1, nullptr, 0);
+    a.in = cur.d; a.sv = savb[q].d; a.l_save = lsv[q];
+    a.work_counter = pc + 5; a.n_saved = pc + 6; a.strag_count = pc + 3 + (q ^ 1); a.strag_out = c->d_strag[q ^ 1];
+    a.strag_in = c->d_strag[q]; a.n_resume = n_x; a.fresh_lo = n_pop; a.long_draws = (unsigned int)Bk; a.budget_trips = 0;
+    // few particles per wave (profiles/r03_tau_vs_lanes.txt), on at most one wave per SIMD of the chip
+    // (alone on the chip -- the pcut waits for them -- one wave per SIMD; beside a main launch every wave they hold is taken from it:
+    // 16 particles per wave cost 12 % on the longest history and 1 / 16 of the slots)
+    const long long waves1 = alone ? (long long)c->n_cu * (threads / 64) : (c->pp_side_waves > 0 ? c->pp_side_waves : (n_x + 15) / 16);
+    long long cm = (n_x + waves1 - 1) / waves1;
+    if (cm > 16) cm = 64;
+    a.claim_max = (int)cm;
+    if (cm < 64) { a.defer_k = 1; a.wait_full = 0; a.tail_merge = 0; }
+    const long long per_block = (long long)(threads / 64) * cm;
+    const long long nb = (n_x + per_block - 1) / per_block;
+    HIPCHK(hipMemcpyAsync(c->pp_dargs + 1, &a, sizeof(KArgs), hipMemcpyHostToDevice, st));
+    HIPCHK(mcs_launch_transport(c->pp_dargs + 1, kind, (int)(nb < full ? nb : full), threads, st));
+    if (!alone) side_blocks += (int)(nb < full ? nb : full);
+    ++c->tail_rounds_last;
+    return 0;
+  };
+  for (int k = 0; k < npc; ++k) {
+    const int i_pcut = i_pcut_first + k, q = k & 1;
+    // ---- the main launch: particles 0 .. nA-1 of the population
+    if (nA > 0) {
+      KArgs& a = c->pp_hargs[0];
+      fill_kargs(c, a, i_pcut, nA, 0, 1, nullptr, Bk > 0 ? 1 : 0);
+      a.in = cur.d; a.sv = savb[q].d; a.l_save = lsv[q];
+      a.work_counter = pc; a.n_saved = pc + 1; a.strag_count = pc + 3 + q; a.strag_out = c->d_strag[q];
+      a.long_draws = (unsigned int)Bk;
+      HIPCHK(hipMemcpyAsync(c->pp_dargs, &a, sizeof(KArgs), hipMemcpyHostToDevice, s1));
+      HIPCHK(hipEventRecord(c->ev0, s1));
+      // (the main launch is persistent and fills every slot of the chip: it leaves room for the side stream's workgroups, which would
+      // otherwise wait for its workgroups to leave -- and run after it instead of beside it)
+      int blocks_a = blocks_for(nA);
+      if (masked) { if (s1 == c->pp_s1m && blocks_a > 2 * (c->n_cu - c->pp_side_cus)) blocks_a = 2 * (c->n_cu - c->pp_side_cus); }
+      else if (side_blocks > 0 && blocks_a > full - side_blocks) blocks_a = (int)(full - side_blocks);
+      HIPCHK(mcs_launch_transport(c->pp_dargs, kind, blocks_a, threads, s1));
+      HIPCHK(hipEventRecord(c->ev1, s1));
+      ++c->tail_rounds_last;
+    }
+    c->rep_dirty = true;
+    // ---- join: the side stream (the previous pcut's long histories, its late split, this pcut's late launch), then the main launch,
+    // the compaction of the particles that were saved and are not long, one read-back
+    const auto tj0 = std::chrono::steady_clock::now();
+    if (side_pending) HIPCHK(hipStreamSynchronize(s2));
+    const auto tj1 = std::chrono::steady_clock::now();
+    if (side_pending) HIPCHK(hipMemcpyAsync(c->pp_hpdl + q, c->pp_dpdl + q, sizeof(PcutDev), hipMemcpyDeviceToHost, s1));
+    // (the late group's size is on the device until here: the compaction below covers every index it can have)
+    const long long n_hi = nA + nL;       // nL: the host's upper bound while side_pending
+    HIPCHK(mcs_launch_compact_match(lsv[q], n_hi, c->d_bcounts, c->d_boffs, pc + 2, c->d_src, 1u, s1));
+    HIPCHK(hipMemcpyAsync(c->pp_hpc, pc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s1));
+    HIPCHK(hipStreamSynchronize(s1));
+    const auto tj2 = std::chrono::steady_clock::now();
+    float ms_main = 0.f;
+    if (nA > 0) { HIPCHK(hipEventElapsedTime(&ms_main, c->ev0, c->ev1)); if (kernel_ms_out) kernel_ms_out[k] = ms_main; ms_sum += ms_main; }
+    const unsigned long long* h = c->pp_hpc;
+    double dbg_wait_ms = 0.0;
+    if (side_pending) {
+      // the previous pcut is complete now: its saved long particles, the size of this pcut's late group
+      const long long n5_prev = c->pp_hpdl[q].n_saved;
+      nL = c->pp_hpdl[q].n_new;
+      n_saved_out[k - 1] = n1_prev + n5_prev;
+      if (sofar_prev + (long long)h[6] != n_saved_out[k - 1]) {
+        static char msg[256];
+        std::snprintf(msg, sizeof msg, "mcs_run_pcuts_pipelined: pcut %d: the kernels' n_saved counters (%lld + %llu resumed) and the count of status bytes (%lld + %lld long) differ",
+                      i_pcut - 1, sofar_prev, (unsigned long long)h[6], n1_prev, n5_prev);
+        return fail(msg);
+      }
+    }
+    side_pending = false;
+    n_use_out[k] = nA + nL;
+    n_done = k + 1;
+    const long long n1 = (long long)h[2], n_T = (long long)h[3 + q];
+    long long sofar = (long long)h[1] + (long long)h[8];        // saved by the main and the late launch: not long, or long and already ended
+    if (strag_out) strag_out[2 * k] = n_T;
+    if (n_T > c->strag_cap) return fail("mcs_run_pcuts_pipelined: export buffer overrun");
+    if (sofar < n1) {
+      static char msg[256];
+      std::snprintf(msg, sizeof msg, "mcs_run_pcuts_pipelined: pcut %d: the kernels' n_saved counters (%llu main + %llu late) are below the count of status bytes (%lld)",
+                    i_pcut, (unsigned long long)h[1], (unsigned long long)h[8], n1);
+      return fail(msg);
+    }
+    const long long target = (long long)n_target[k];
+    const bool last = k == npc - 1;
+    long long n_open = n_T;                 // exported particles that have not been resumed yet
+    if (sofar + n_T == 0) { n_saved_out[k] = 0; break; }                       // nobody left: the species ends here
+    const long long im_hi = target / (sofar + n_T) > 1 ? target / (sofar + n_T) : 1;
+    const long long im_lo = sofar > 0 ? (target / sofar > 1 ? target / sofar : 1) : -1;
+    // (more long histories than the side stream's CUs hold at 16 per wave, twice over: beside the main launch they would outlast it)
+    const long long side_cap = masked ? (long long)c->pp_side_cus * 8 * 16 * 2 : (long long)c->pp_side_max * 4 * 16 * 2;
+    if ((last || im_lo != im_hi || n_T > side_cap) && n_T > 0) {
+      // i_mult depends on how many of the long histories end saved (or this is the last pcut, or they are too many): they finish first
+      HIPCHK(hipMemsetAsync(pc + 5, 0, 2 * sizeof(unsigned long long), s_alone));
+      if (launch_resume(i_pcut, q, nA + nL, n_T, s_alone, true)) return 1;
+      HIPCHK(hipMemcpyAsync(c->pp_hpc + 6, pc + 6, sizeof(unsigned long long), hipMemcpyDeviceToHost, s_alone));
+      const auto tw0 = std::chrono::steady_clock::now();
+      HIPCHK(hipStreamSynchronize(s_alone));
+      dbg_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+      sofar += (long long)c->pp_hpc[6];
+      n_open = 0;
+      if (strag_out) strag_out[2 * k + 1] = 1;
+      ++c->pp_waits_last;
+    }
+    if (dbg_pipe)
+      std::fprintf(stderr, "[pipe] pcut %2d n_use %8lld (late %7lld) main %6.2f ms | side-sync %6.2f ms main-sync %6.2f ms | saved so far %8lld exported %6lld %s %6.2f ms\n",
+                   i_pcut, nA + nL, nL, ms_main, std::chrono::duration<double, std::milli>(tj1 - tj0).count(),
+                   std::chrono::duration<double, std::milli>(tj2 - tj1).count(), sofar, n_T, n_open == 0 && n_T > 0 ? "WAITED" : "      ", dbg_wait_ms);
+    if (sofar + n_open == 0) { n_saved_out[k] = 0; break; }                  // (the long histories all ended: the species ends here)
+    const long long i_mult = target / (sofar + n_open) > 1 ? target / (sofar + n_open) : 1;     // (== for both bounds when n_open > 0)
+    i_mult_out[k] = i_mult;
+    n_saved_out[k] = sofar;                 // (complete unless long histories are still open: then the next join adds those that end saved)
+    if (last || sofar + n_open == 0) break;
+    const long long B_next = (long_imult_max <= 0 || i_mult <= long_imult_max) ? long_draws : 0;
+    // ---- the next pcut: main group = children of the saved particles that are not long; late group = children of the saved long ones
+    const long long nA_next = n1 * i_mult;
+    const long long n5_max = sofar - n1 + n_open;               // long particles that are saved, or still running
+    const long long nL_max = n5_max * i_mult;
+    // ((sofar + n_open) * i_mult <= max(n_target, sofar + n_open) <= cap_n: every buffer holds it)
+    if (nA_next + nL_max > cap_n) return fail("mcs_run_pcuts_pipelined: the next population exceeds the buffers");
+    // (the long histories go first: their few waves must be resident before the next main launch fills every slot of the chip --
+    // queued behind it they would start when its workgroups leave, i.e. run after it instead of beside it.  Their counters are the side
+    // stream's own words; everything else is cleared on the main stream, and the late split / late launch wait for that.)
+    side_blocks = 0;
+    s1 = (masked && n5_max > 0) ? c->pp_s1m : c->stream;      // (both are idle: the join synchronised the host with every stream)
+    if (n5_max > 0) {
+      HIPCHK(hipMemsetAsync(pc + 5, 0, 2 * sizeof(unsigned long long), s2));
+      if (n_open > 0 && launch_resume(i_pcut, q, nA + nL, n_open, s2, false)) return 1;
+    }
+    HIPCHK(hipMemsetAsync(pc, 0, 5 * sizeof(unsigned long long), s1));
+    HIPCHK(hipMemsetAsync(pc + 7, 0, 3 * sizeof(unsigned long long), s1));
+    if (nA_next + nL_max > 0) HIPCHK(hipMemsetAsync(lsv[q ^ 1], 0, (size_t)(nA_next + nL_max), s1));
+    HIPCHK(hipEventRecord(c->pp_reset, s1));
+    HIPCHK(mcs_launch_split(savb[q].d, nxt.d, c->d_src, nA_next, i_mult, s1));
+    n1_prev = n1; sofar_prev = sofar;
+    if (n5_max > 0) {
+      HIPCHK(hipStreamWaitEvent(s2, c->pp_reset, 0));
+      DevPop out = nxt.d;
+      out.weight += nA_next; out.ptot_pf += nA_next; out.pb_pf += nA_next; out.x_PT_cm += nA_next; out.xn_per += nA_next;
+      out.prp_x_cm += nA_next; out.acctime_sec += nA_next; out.phi_rad += nA_next; out.meta += nA_next;
+      const int split_blocks = (int)std::min<long long>((nL_max + 255) / 256, (long long)c->n_cu * 4);
+      HIPCHK(mcs_launch_late_split(lsv[q], nA + nL, c->pp_bcounts, c->pp_boffs, pc + 9, c->pp_src, c->pp_dpdl + (q ^ 1), i_mult, nA_next, savb[q].d,
+                                   out, split_blocks < 1 ? 1 : split_blocks, s2));
+      // the late launch of the next pcut: particles nA_next .. of its population, their number read on the device
+      KArgs& a = c->pp_hargs[2];
+      fill_kargs(c, a, i_pcut + 1, nA_next, 0, 1, nullptr, B_next > 0 ? 1 : 0);
+      a.in = nxt.d; a.sv = savb[q ^ 1].d; a.l_save = lsv[q ^ 1];
+      a.n_dev = &c->pp_dpdl[q ^ 1].n_use; a.fresh_lo = nA_next;
+      a.work_counter = pc + 7; a.n_saved = pc + 8; a.strag_count = pc + 3 + (q ^ 1); a.strag_out = c->d_strag[q ^ 1];
+      a.long_draws = (unsigned int)B_next;
+      HIPCHK(hipMemcpyAsync(c->pp_dargs + 2, &a, sizeof(KArgs), hipMemcpyHostToDevice, s2));
+      HIPCHK(mcs_launch_transport(c->pp_dargs + 2, kind, blocks_for(nL_max), threads, s2));
+      side_blocks += blocks_for(nL_max);
+      if (side_blocks > c->pp_side_max) side_blocks = c->pp_side_max;
+      ++c->tail_rounds_last;
+      side_pending = true;
+      nL = nL_max;
+    } else {
+      nL = 0;
+    }
+    nA = nA_next;
+    Bk = B_next;
+    PopBuf t = cur; cur = nxt; nxt = t;
+  }
+  if (side_pending) HIPCHK(hipStreamSynchronize(s2));      // (only after an error path: every exit above leaves the side stream idle)
+  HIPCHK(hipStreamSynchronize(s1));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->cur = cur; c->spare = nxt;
+  c->n = n_done > 0 ? n_use_out[n_done - 1] : c->n;
+  c->n_run_last = -1; c->n_saved_last = 0;
+  c->last_ms = ms_sum;
+  c->kernel_last = kind;
   return 0;
 }
 

@@ -72,6 +72,12 @@ struct KArgs {
   int ws_serve_min;          // ... and the number of pending particles at which a wave serves them (64)
   int claim_max;             // live particles a wave holds at most (64; less spreads a sparse queue over the waves of the chip:
                              // a pass costs a wave the same with 1 live lane as with 64, but every live lane's rare work stalls the others)
+  // ---- long histories (mcs_run_pcuts_pipelined; DESIGN.md "Pipelined pcuts").  A particle is LONG in a pcut when it has taken at least
+  // `long_draws` random draws by the end of its history there -- a property of the particle alone (its stream position), whatever the
+  // schedule.  A sliced launch with long_draws > 0 exports a wave's live particles once the queue is exhausted and every one of them has
+  // reached long_draws (so everything exported is long; `budget_trips` only has to be non-zero), and every particle's status byte carries
+  // the verdict: l_save = 1 saved, 2 ended, + 4 when long.  0: off.
+  unsigned int long_draws;
 };
 
 // Replicas of the tally buffer.  Particles of one population pile their tallies onto

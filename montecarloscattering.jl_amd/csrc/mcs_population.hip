@@ -42,14 +42,14 @@ __device__ __forceinline__ double philox_uniform(unsigned long long key, uint32_
 // ---------------------------------------------------------------------------------
 // K2a: per-block count of saved flags.  1024 elements per 256-thread block.
 extern "C" __global__ void __launch_bounds__(256)
-mcs_k_count_saved(const uint8_t* __restrict__ l_save, long long n, unsigned int* __restrict__ block_counts) {
+mcs_k_count_saved(const uint8_t* __restrict__ l_save, long long n, unsigned int* __restrict__ block_counts, unsigned int match) {
   __shared__ unsigned int wsum[4];
   const long long base = (long long)blockIdx.x * 1024;
   unsigned int c = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long i = base + r * 256 + threadIdx.x;
-    const bool f = i < n && l_save[i] == 1;
+    const bool f = i < n && l_save[i] == match;      // (the status byte: 1 saved; 5 saved and long, see KArgs::long_draws)
     c += (unsigned int)__popcll(__ballot(f));     // wave-uniform count
   }
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -87,7 +87,7 @@ mcs_k_scan_blocks(const unsigned int* __restrict__ counts, long long nb, unsigne
 // K2c: stable compaction: src[rank] = index of the rank-th saved particle.
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_compact_index(const uint8_t* __restrict__ l_save, long long n, const unsigned long long* __restrict__ offsets,
-                    long long* __restrict__ src) {
+                    long long* __restrict__ src, unsigned int match) {
   __shared__ unsigned int wcount[4][4];   // [round][wave]
   const long long base = (long long)blockIdx.x * 1024;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -96,7 +96,7 @@ mcs_k_compact_index(const uint8_t* __restrict__ l_save, long long n, const unsig
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long i = base + r * 256 + threadIdx.x;
-    f[r] = i < n && l_save[i] == 1;
+    f[r] = i < n && l_save[i] == match;
     m[r] = __ballot(f[r]);
     if (lane == 0) wcount[r][wave] = (unsigned int)__popcll(m[r]);
   }
@@ -177,6 +177,14 @@ extern "C" __global__ void mcs_k_pcut_decide(PcutDev* __restrict__ pd, PcutDev* 
   pd->n_saved = ns; pd->i_mult = im; pd->n_new = ns * im;
   if (pd_next) pd_next->n_use = ns * im;
   counters[0] = 0ull; counters[1] = 0ull;
+}
+// the late group of a pipelined pcut (mcs_run_pcuts_pipelined): the saved LONG particles are known only when the stragglers have finished,
+// on the side stream -- their number, the size of their split and the population size the late launch of the next pcut reads.  One thread.
+extern "C" __global__ void mcs_k_late_decide(PcutDev* __restrict__ pd, const unsigned long long* __restrict__ scan_total, long long i_mult,
+                                             long long n_main_next) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long ns = (long long)*scan_total;
+  pd->n_saved = ns; pd->i_mult = i_mult; pd->n_new = ns * i_mult; pd->n_use = n_main_next + ns * i_mult;
 }
 extern "C" __global__ void __launch_bounds__(256)
 mcs_k_split_dev(DevPop sv, DevPop out, const long long* __restrict__ src, const PcutDev* __restrict__ pd) {
@@ -340,13 +348,27 @@ extern "C" {
 // the compaction half of new_pcut: src[r] = local index of the r-th saved particle, *total_dev = their number.
 // Queued right behind the transport kernel by mcs_run_pcut, so that ONE read-back brings both the kernel's own
 // n_saved counter and this independent count of l_save (they must agree) and nothing has to be waited for later.
-hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
-                              unsigned long long* total_dev, long long* src, hipStream_t st) {
+hipError_t mcs_launch_compact_match(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                    unsigned long long* total_dev, long long* src, unsigned int match, hipStream_t st) {
   const long long nb = (n + 1023) / 1024;
   if (nb == 0) return hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), st);
-  hipLaunchKernelGGL(mcs_k_count_saved, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_counts);
+  hipLaunchKernelGGL(mcs_k_count_saved, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_counts, match);
   hipLaunchKernelGGL(mcs_k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets, total_dev);
-  hipLaunchKernelGGL(mcs_k_compact_index, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_offsets, src);
+  hipLaunchKernelGGL(mcs_k_compact_index, dim3((unsigned)nb), dim3(256), 0, st, l_save, n, block_offsets, src, match);
+  return hipGetLastError();
+}
+hipError_t mcs_launch_compact(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                              unsigned long long* total_dev, long long* src, hipStream_t st) {
+  return mcs_launch_compact_match(l_save, n, block_counts, block_offsets, total_dev, src, 1u, st);
+}
+// the late group of a pipelined pcut: compaction of the saved LONG particles (status 5), their split behind the main group's children
+hipError_t mcs_launch_late_split(const uint8_t* l_save, long long n, unsigned int* block_counts, unsigned long long* block_offsets,
+                                 unsigned long long* total_dev, long long* src, PcutDev* pd, long long i_mult, long long n_main_next, DevPop sv,
+                                 DevPop out_at_main_end, int split_blocks, hipStream_t st) {
+  hipError_t e = mcs_launch_compact_match(l_save, n, block_counts, block_offsets, total_dev, src, 5u, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(mcs_k_late_decide, dim3(1), dim3(64), 0, st, pd, total_dev, i_mult, n_main_next);
+  hipLaunchKernelGGL(mcs_k_split_dev, dim3((unsigned)split_blocks), dim3(256), 0, st, sv, out_at_main_end, src, pd);
   return hipGetLastError();
 }
 // one pcut's pcut_finalize + new_pcut with the sizes on the device (see mcs_k_pcut_decide); cap_n: the largest population possible

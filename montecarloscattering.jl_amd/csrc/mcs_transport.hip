@@ -1707,6 +1707,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   const unsigned long long n = n_resume + (unsigned long long)(n_pop - fresh_lo);
   const unsigned budget = SLICED ? (unsigned)__builtin_amdgcn_readfirstlane(a->budget_trips) : 0u;
   const int claim_max = SLICED ? __builtin_amdgcn_readfirstlane(a->claim_max) : 64;
+  const unsigned long_draws = SLICED ? (unsigned)__builtin_amdgcn_readfirstlane((int)a->long_draws) : 0u;
   unsigned mtick_ex = 0;            // mtick when this wave found the queue exhausted
 
   const unsigned wv = threadIdx.x >> 6;
@@ -1866,7 +1867,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         mrole = 0; mpoll_mask = budget != 0u ? MCS_MERGE_POLL_MASK : ~0u;
       };
       // (a sliced launch whose budget is spent exports below: the pair is closed first, a donation already made is taken and exported too)
-      const bool closing = SLICED && budget != 0u && exhausted && mtick - mtick_ex >= budget;
+      // (long_draws: the wave closes when every live particle has become long -- see KArgs -- instead of after a number of trips)
+      const bool closing = SLICED && budget != 0u && exhausted &&
+                           (long_draws != 0u ? __builtin_amdgcn_ballot_w64(active && rng.n < long_draws) == 0ull : mtick - mtick_ex >= budget);
       if (mrole != 0 && exhausted) {
         unsigned mpartner;
         const unsigned mpair = pair_of(mpartner);
@@ -1908,7 +1911,10 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       }
       // ---- sliced launches: the budget of trips after exhaustion is spent -- the live particles go to the export buffer
       // (complete lane state, mid-history) and the wave ends; a later launch resumes them
-      if (closing) {
+      // (long_draws: a donation taken just above may have brought particles that are not long yet -- everything exported must be long,
+      // the order of the next population hangs on it -- so the test is made again on the lanes as they are now; the pair is closed, the
+      // wave comes back at the next poll)
+      if (closing && (long_draws == 0u || __builtin_amdgcn_ballot_w64(active && rng.n < long_draws) == 0ull)) {
         const unsigned long long am_x = __builtin_amdgcn_ballot_w64(active);
         if (am_x != 0ull) {
           const int nlive = __popcll(am_x);
@@ -2095,7 +2101,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         atomicAdd(&S_steps[2], (unsigned long long)rng.n);
         if (p.n_ovr) cnt(a, MCS_IC_TCUT_OVERRUN, p.n_ovr);
         if (end == 0) {
-          a->l_save[k] = 1;
+          a->l_save[k] = SLICED ? (uint8_t)(1u | ((long_draws != 0u && rng.n >= long_draws) ? 4u : 0u)) : (uint8_t)1;
           a->sv.weight[k] = p.weight; a->sv.ptot_pf[k] = p.ptot_pf; a->sv.pb_pf[k] = p.pb_pf; a->sv.x_PT_cm[k] = p.x;
           a->sv.xn_per[k] = p.xn_per;
           a->sv.prp_x_cm[k] = p.x < p.prp ? p.prp : p.x * 1.1;   // quirk Q7
@@ -2103,7 +2109,8 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
           a->sv.meta[k] = mcs_pack_meta(p.i_grid, p.tcut, p.downstream, p.inj);
           cnt(a, MCS_IC_COUNT);
         } else {
-          a->l_save[k] = 2;     // (status byte: 1 saved, 2 ended; 0 = not resolved yet, which only a sliced run ever sees)
+          // (status byte: 1 saved, 2 ended, + 4 long -- KArgs::long_draws; 0 = not resolved yet, which only a sliced run ever sees)
+          a->l_save[k] = SLICED ? (uint8_t)(2u | ((long_draws != 0u && rng.n >= long_draws) ? 4u : 0u)) : (uint8_t)2;
           if (p.npush < 2) {
             // particle_finish! (transform, two bin look-ups, up to five tallies) is deferred like the zone-crossing
             // tallies: a record on the wave's stack, tallied 64 at a time (a lane pushes at most two records per pass)
@@ -2294,6 +2301,10 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_sliced(const KArgs* __restrict__ ka) {
   transport_body<false, false, false, true>(ka);
 }
+// the sliced form of the PLAIN kernel: what the pipelined pcut loop launches for the common configuration (mcs_run_pcuts_pipelined)
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain_sliced(const KArgs* __restrict__ ka) {
+  transport_body<true, false, false, true>(ka);
+}
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
@@ -2318,6 +2329,7 @@ extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blo
   else if (kind == 2) hipLaunchKernelGGL(mcs_k_transport_lossy, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 6) hipLaunchKernelGGL(mcs_k_transport_plain_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 10) hipLaunchKernelGGL(mcs_k_transport_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 11) hipLaunchKernelGGL(mcs_k_transport_plain_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 7) hipLaunchKernelGGL(mcs_k_transport_ws, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 8) hipLaunchKernelGGL(mcs_k_transport_ws_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);

@@ -135,7 +135,8 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
         verbose: bool = False, gather_max: int = 1 << 17, skew_max: float = 1.1,
         finalize: bool = False, smoothing=None, on_iteration_end: Optional[Callable] = None,
         first_iter: int = 1, iter_state=None, species_tallies: str = "full", final_full_read: bool = True,
-        before_pcut: Optional[Callable] = None, tcut_print: bool = False, fused_pcuts: bool = True) -> RunResult:
+        before_pcut: Optional[Callable] = None, tcut_print: bool = False, fused_pcuts: bool = True, long_draws: Optional[int] = None,
+        long_imult_max: Optional[int] = None) -> RunResult:
     """Run `n_itrs` iterations of all species through all pcuts.
 
     backend protocol: create/begin_iteration/begin_species/set_fluxes/init_pop/
@@ -175,6 +176,10 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
     # rank > 0 keeps only its local partial sums: everything it contributes is a delta
     is_root = comm.rank == 0
     multi = comm.enabled          # (a forced one-rank group runs the multi-rank path too: bench.py MCS_BENCH_FORCE_COMM)
+    if long_draws is None:
+        long_draws = int(os.environ.get("MCS_LONG_DRAWS", "0")) if not multi else 0
+    if long_imult_max is None:
+        long_imult_max = int(os.environ.get("MCS_LONG_IMULT_MAX", "8"))
     G_f = G_i = None
     # Live device tensors of the tallies (HIP backend with torch_tallies): the multi-GPU merge
     # then runs in place on the device (RCCL all-reduce, no host round trip).  Otherwise
@@ -252,6 +257,37 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
             # the next population's size are decided there (mcs_run_pcuts_fused), one read-back per species instead of one per pcut.
             fused = (fused_pcuts and not multi and before_pcut is None and hasattr(backend, "run_pcuts_fused") and n_pcuts >= 1
                      and os.environ.get("MCS_FUSED_PCUTS", "1") != "0")
+            # Long histories told apart (long_draws > 0; MCS_LONG_DRAWS): the next population is ordered non-long before long, which lets a
+            # pcut's long histories finish beside the next pcut (mcs_run_pcuts_pipelined; one rank).  A backend without that entry point
+            # (the oracle) is told the order (set_long_draws) and runs the ordinary loop: same populations, same streams, same results.
+            if long_draws:
+                if multi:
+                    raise ValueError("long_draws: the pipelined pcut loop and its population order are single-rank (one process per replica)")
+                if not hasattr(backend, "run_pcuts_pipelined") and not hasattr(backend, "set_long_draws"):
+                    raise ValueError("long_draws: the backend can neither pipeline the pcuts nor order the population by history length")
+            pipelined = bool(long_draws) and before_pcut is None and hasattr(backend, "run_pcuts_pipelined") and n_pcuts >= 1 and not getattr(P, "state_fp32", 0)
+            if long_draws and not pipelined:
+                if not hasattr(backend, "set_long_draws"):
+                    raise ValueError("long_draws: this configuration runs the per-pcut loop, and the backend cannot order the population there")
+                backend.set_long_draws(int(long_draws))
+            i_mult_prev = 0                 # (the rule of mcs_run_pcuts_pipelined for the per-pcut loop: see long_imult_max)
+            if pipelined:
+                fused = False
+                t0 = time.perf_counter()
+                targets = [cfg.N_PTS_PCUT if prob.pcuts[ip - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI for ip in range(1, n_pcuts + 1)]
+                n_use_a, n_saved_a, i_mult_a, ms_a, strag_a = backend.run_pcuts_pipelined(1, n_pcuts, targets, int(long_draws), int(long_imult_max))
+                wall = (time.perf_counter() - t0) * 1e3
+                n_done = n_pcuts
+                for ip in range(1, n_pcuts + 1):
+                    if int(n_saved_a[ip - 1]) == 0:
+                        n_done = ip
+                        break
+                for ip in range(1, n_done + 1):
+                    nu, nsv, im = int(n_use_a[ip - 1]), int(n_saved_a[ip - 1]), int(i_mult_a[ip - 1])
+                    stats.append(PcutStat(i_iter, i_ion, ip, nu, nsv, im if nsv > 0 else 0, nu, "-", float(ms_a[ip - 1]), wall / max(n_done, 1)))
+                    if verbose and is_root:
+                        print(f"[iter {i_iter} ion {i_ion} pcut {ip:2d}] n_use={nu} n_saved={nsv} i_mult={im} kernel={ms_a[ip - 1]:.2f} ms "
+                              f"(pipelined: {int(strag_a[ip - 1][0])} long histories exported{', waited' if strag_a[ip - 1][1] else ''})", flush=True)
             if fused:
                 t0 = time.perf_counter()
                 targets = [cfg.N_PTS_PCUT if prob.pcuts[ip - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI for ip in range(1, n_pcuts + 1)]
@@ -276,10 +312,12 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                     if last:
                         empty_launches.extend((i_iter, i_ion, jp, float(ms_a[jp - 1])) for jp in range(ip + 1, n_done + 1))
                         break
-            for i_pcut in (() if fused else range(1, n_pcuts + 1)):
+            for i_pcut in (() if (fused or pipelined) else range(1, n_pcuts + 1)):
                 t0 = time.perf_counter()
                 if before_pcut is not None:
                     before_pcut(i_iter, i_ion, i_pcut)
+                if long_draws and not pipelined:
+                    backend.set_long_draws(int(long_draws) if (i_pcut == 1 or long_imult_max <= 0 or i_mult_prev <= long_imult_max) else 0)
                 if gidx is not None:
                     n_saved_local = backend.run_pcut_indexed(i_pcut, gidx)
                 else:
@@ -294,6 +332,7 @@ def run(prob: Problem, backend, comm: Optional[Comm] = None, n_itrs: Optional[in
                 if n_saved > 0:
                     n_target = cfg.N_PTS_PCUT if prob.pcuts[i_pcut - 1] < p_pcut_hi else cfg.N_PTS_PCUT_HI
                     i_mult = max(n_target // n_saved, 1)         # new_pcut, src/cuts.jl:42
+                i_mult_prev = i_mult
                 last = n_saved == 0 or i_pcut == n_pcuts
                 local_ok = not multi or (n_saved > gather_max and max(counts) * comm.world <= skew_max * n_saved)
                 st = PcutStat(i_iter, i_ion, i_pcut, n_use_global, n_saved, i_mult, n_use_max,

@@ -269,6 +269,22 @@ class HipBackend:
                                                ns.ctypes.data_as(c_int64_p), im.ctypes.data_as(c_int64_p), _dp(ms)))
         return nu, ns, im, ms
 
+    def run_pcuts_pipelined(self, i_pcut_first: int, i_pcut_last: int, n_target, long_draws: int, long_imult_max: int = 0):
+        """mcs_run_pcuts_pipelined: the pcuts first .. last of the current species with every pcut's long histories (>= long_draws random
+        draws) finishing beside the next pcut on a second stream -> (n_use, n_saved, i_mult, kernel_ms, strag[npc][2]) per pcut; strag:
+        particles exported, and 1 where i_mult had to wait for them.  The next population is ordered non-long before long (include/mcs.h);
+        long_imult_max > 0: only in pcuts whose predecessor split by at most that factor."""
+        npc = i_pcut_last - i_pcut_first + 1
+        tg = np.ascontiguousarray(n_target, dtype=np.int64)
+        assert tg.shape == (npc,)
+        nu, ns, im = (np.zeros(npc, dtype=np.int64) for _ in range(3))
+        ms = np.zeros(npc)
+        sg = np.zeros((npc, 2), dtype=np.int64)
+        self._chk(self.lib.mcs_run_pcuts_pipelined(self.h, int(i_pcut_first), int(i_pcut_last), tg.ctypes.data_as(c_int64_p), int(long_draws), int(long_imult_max),
+                                                   nu.ctypes.data_as(c_int64_p), ns.ctypes.data_as(c_int64_p), im.ctypes.data_as(c_int64_p), _dp(ms),
+                                                   sg.ctypes.data_as(c_int64_p)))
+        return nu, ns, im, ms, sg
+
     def read_counters(self):
         """The int64 tallies alone (num_crossings + event counters: ~1 KB), no fp64 word."""
         i = np.zeros(self.layout.n_i64, dtype=np.int64)

@@ -60,6 +60,9 @@ def load(math: str = "det", capi=None):
         "orc_scattering": (None, [vp, ct.c_uint64, dbl, dbl, dbl, dbl, dbl, dp, dp, dp, dp]),
         "orc_transform_p_PS": (None, [dbl] * 11 + [dp]),
         "orc_transform_p_PSP": (None, [vp] + [dbl] * 5 + [dp, dp, dp]),
+        "orc_set_long_draws": (i32, [vp, i64]),
+        "orc_count_long": (i64, [vp, u8p, i64]),
+        "orc_new_pcut_ordered": (i64, [vp, i64, i64, u8p, soa_p, soa_p]),
         "orc_bin_momentum": (i32, [vp, dbl]),
         "orc_bin_angle": (i32, [vp, dbl, dbl]),
         # oracle/mcs_iter.cpp: the CPU twin of montecarloscattering.jl_amd/iter_finalize.py
@@ -246,10 +249,25 @@ class OracleBackend:
                                       retro.ctypes.data_as(i32p), _dp(ptot), _dp(x)))
         return dict(reason=reason, helix=helix, retro=retro, ptot=ptot, x=x)
 
+    def set_long_draws(self, long_draws):
+        """Tell long histories apart (>= long_draws random draws in a pcut): new_pcut then orders the children of the saved particles that
+        are not long before those of the saved long ones -- the order mcs_run_pcuts_pipelined produces.  0: the reference's order."""
+        self.long_draws = int(long_draws)
+        self._chk(self.lib.orc_set_long_draws(self.h, int(long_draws)))
+
+    def count_long_saved(self):
+        return int(self.lib.orc_count_long(self.h, self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)), len(self.l_save)))
+
     def new_pcut(self, i_mult):
         n_saved = int(self.l_save.sum())
         out = self.capi.Population(n_saved * i_mult)
         ss, so = self.saved.soa(), out.soa()
+        if getattr(self, "long_draws", 0):
+            n_new = self.lib.orc_new_pcut_ordered(self.h, self.pop.n, i_mult, self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)),
+                                                  ct.byref(ss), ct.byref(so))
+            assert n_new == out.n
+            self.pop = out
+            return int(n_new)
         n_new = self.lib.orc_new_pcut(self.pop.n, i_mult, self.l_save.ctypes.data_as(ct.POINTER(ct.c_uint8)),
                                       ct.byref(ss), ct.byref(so))
         assert n_new == out.n
