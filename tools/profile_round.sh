@@ -7,7 +7,7 @@ TAG=$1; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run_passes () {   # $1 = label, $2.. = bench arguments
   L=$1; shift
-  CMD="python $GRAFT_REPO_ROOT/bench.py $* --no-cpu --overlap 1"     # (--overlap 1: without the extra overlapped leg, whose launches have another geometry: the kernel statistics then cover exactly the launches of the warm-up and timed iterations)
+  CMD="python $GRAFT_REPO_ROOT/bench.py $* --no-cpu --overlap 1 --long-draws 0"     # (--overlap 1, --long-draws 0: without the extra overlapped and pipelined legs, whose launches have another geometry / another kernel: the kernel statistics then cover exactly the launches of the warm-up and timed iterations)
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$L -- $CMD > $OUT/stats_$L.log 2>&1
   timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$L -- $CMD > $OUT/fetch_$L.log 2>&1
   timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$L -- $CMD > $OUT/write_$L.log 2>&1
