@@ -1094,6 +1094,7 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
     ++c->tail_rounds_last;
     return 0;
   };
+  int rc = 0;                        // (a failed cross-check ends the loop: the streams are drained below before the error is returned)
   for (int k = 0; k < npc; ++k) {
     const int i_pcut = i_pcut_first + k, q = k & 1;
     // ---- the main launch: particles 0 .. nA-1 of the population
@@ -1140,7 +1141,7 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
         static char msg[256];
         std::snprintf(msg, sizeof msg, "mcs_run_pcuts_pipelined: pcut %d: the kernels' n_saved counters (%lld + %llu resumed) and the count of status bytes (%lld + %lld long) differ",
                       i_pcut - 1, sofar_prev, (unsigned long long)h[6], n1_prev, n5_prev);
-        return fail(msg);
+        rc = fail(msg); side_pending = false; break;
       }
     }
     side_pending = false;
@@ -1149,12 +1150,12 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
     const long long n1 = (long long)h[2], n_T = (long long)h[3 + q];
     long long sofar = (long long)h[1] + (long long)h[8];        // saved by the main and the late launch: not long, or long and already ended
     if (strag_out) strag_out[2 * k] = n_T;
-    if (n_T > c->strag_cap) return fail("mcs_run_pcuts_pipelined: export buffer overrun");
+    if (n_T > c->strag_cap) { rc = fail("mcs_run_pcuts_pipelined: export buffer overrun"); break; }
     if (sofar < n1) {
       static char msg[256];
       std::snprintf(msg, sizeof msg, "mcs_run_pcuts_pipelined: pcut %d: the kernels' n_saved counters (%llu main + %llu late) are below the count of status bytes (%lld)",
                     i_pcut, (unsigned long long)h[1], (unsigned long long)h[8], n1);
-      return fail(msg);
+      rc = fail(msg); break;
     }
     const long long target = (long long)n_target[k];
     const bool last = k == npc - 1;
@@ -1192,7 +1193,7 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
     const long long n5_max = sofar - n1 + n_open;               // long particles that are saved, or still running
     const long long nL_max = n5_max * i_mult;
     // ((sofar + n_open) * i_mult <= max(n_target, sofar + n_open) <= cap_n: every buffer holds it)
-    if (nA_next + nL_max > cap_n) return fail("mcs_run_pcuts_pipelined: the next population exceeds the buffers");
+    if (nA_next + nL_max > cap_n) { rc = fail("mcs_run_pcuts_pipelined: the next population exceeds the buffers"); break; }
     // (the long histories go first: their few waves must be resident before the next main launch fills every slot of the chip --
     // queued behind it they would start when its workgroups leave, i.e. run after it instead of beside it.  Their counters are the side
     // stream's own words; everything else is cleared on the main stream, and the late split / late launch wait for that.)
@@ -1245,7 +1246,7 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
   c->n_run_last = -1; c->n_saved_last = 0;
   c->last_ms = ms_sum;
   c->kernel_last = kind;
-  return 0;
+  return rc;
 }
 
 int mcs_new_pcut(mcs_ctx* c, int64_t i_mult, int64_t* n_new_out) {
