@@ -1238,7 +1238,7 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
     Bk = B_next;
     PopBuf t = cur; cur = nxt; nxt = t;
   }
-  if (side_pending) HIPCHK(hipStreamSynchronize(s2));      // (only after an error path: every exit above leaves the side stream idle)
+  HIPCHK(hipStreamSynchronize(s2));      // (idle already on every exit but a failed cross-check)
   HIPCHK(hipStreamSynchronize(s1));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->cur = cur; c->spare = nxt;
