@@ -339,7 +339,11 @@ def main():
         if overlap_leg:
             out["overlapped_iterations"] = overlapped_leg(mcs, hip_backend, prob, be, local, args)
         if pipe_leg:
-            out["pipelined_pcuts"] = pipelined_leg(mcs, prob, be, args, pipe_first, sm)
+            # (an extra leg must never cost the headline line: a failure is reported in its place)
+            try:
+                out["pipelined_pcuts"] = pipelined_leg(mcs, prob, be, args, pipe_first, sm)
+            except Exception as e:      # noqa: BLE001
+                out["pipelined_pcuts"] = {"error": f"{type(e).__name__}: {e}"}
         if args.mixed and world == 1:
             # the photon leg of config[4] ("inverse-Compton/synch photon tallies"): ion_finalize's photon_calcs for the electron
             # species on the histograms the last iteration left on the device (K4 dN/dp, K5 synchrotron, K6 get_dNdp_2D + IC).
