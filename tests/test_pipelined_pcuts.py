@@ -114,6 +114,22 @@ def test_gpu_pipelined_loop_equals_the_oracle_in_the_same_order(N, B, imax):
 
 
 @pytest.mark.gpu
+def test_gpu_pipelined_loop_over_iterations_and_tiny_populations():
+    """two iterations on one context (buffers, streams and counters are reused), and populations smaller than a workgroup"""
+    from conftest import hip_backend
+    for N, B in ((2500, 600), (48, 200)):
+        prob = make_problem(N, num_iterations=2)
+        ob = oracle_backend(prob, nthreads=16)
+        ro = mcs.driver.run(prob, ob, n_itrs=2, long_draws=B, long_imult_max=8)
+        hb = hip_backend(prob)
+        rg = mcs.driver.run(prob, hb, n_itrs=2, long_draws=B, long_imult_max=8)
+        assert _stats(ro) == _stats(rg) and len({s.i_iter for s in rg.stats}) == 2
+        assert np.array_equal(ro.tallies_i64, rg.tallies_i64)
+        assert_tallies_close(mcs.capi.Layout(prob.params), ro.tallies_f64, rg.tallies_f64, rtol=1e-11)
+        ob.destroy(); hb.destroy()
+
+
+@pytest.mark.gpu
 def test_gpu_pipelined_loop_without_long_histories_equals_the_per_pcut_loop():
     """A long_draws nobody reaches: no export, no late group -- the machinery alone (two sets of saved arrays, the masked streams, the
     split by status byte) must reproduce the per-pcut loop."""
