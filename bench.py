@@ -223,7 +223,7 @@ def main():
     # (room in the per-iteration tallies for the iterations of the extra overlapped leg, which carry on the numbering)
     overlap_leg = world == 1 and not force_comm and args.overlap > 1 and not args.smooth and not args.mixed and not args.fp32
     n_extra = (2 * args.overlap + args.steps) if overlap_leg else 0
-    pipe_leg = world == 1 and not force_comm and args.long_draws > 0 and not args.mixed and not args.fp32
+    pipe_leg = world == 1 and not force_comm and args.long_draws > 0 and not args.mixed and not args.fp32 and not args.smooth
     pipe_first = n_itrs + n_extra + 1
     if pipe_leg:
         n_extra += 1 + args.steps
