@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--species-tallies", choices=("light", "full"), default="light",
                     help="what the host fetches at every species end: the 0.8 MB it computes with (light) or the whole 61 MB buffer (full)")
-    ap.add_argument("--overlap", type=int, default=2,
+    ap.add_argument("--overlap", type=int, default=3,
                     help="extra leg, reported beside `value` and never in it: this many independent iterations in flight (driver.run_overlapped); 1 = skip")
     ap.add_argument("--long-draws", type=int, default=8192,
                     help="extra leg at N=1 (not the headline): the pcuts pipelined, long histories = this many random draws (0: skip)")
