@@ -535,8 +535,10 @@ def run_overlapped(prob: Problem, backends, n_itrs: Optional[int] = None, max_pc
                     alone = state["busy"] <= 1
                     be.set_launch(0 if alone else int(blocks_per_launch), 0 if alone else 256)
             try:
+                # (long_draws=0: the pcuts are not pipelined here -- the other iterations' launches are what fills this one's tails, and
+                # the per-pcut hook needs the per-pcut loop; MCS_LONG_DRAWS does not reach this call)
                 res = run(prob, be, None, n_itrs=1, max_pcuts=max_pcuts, first_iter=i_iter, species_tallies="light", final_full_read=False,
-                          before_pcut=geometry)
+                          before_pcut=geometry, long_draws=0)
                 ion_fin = consumers.ion_finalize(prob, be, len(cfg.species))     # K4, before the context is reused
             finally:
                 with state_lock:
