@@ -184,7 +184,7 @@ def photon_synch(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: flo
     src/synch_emission.jl over the plasma-frame dN/dp (frame 2 of get_dNdp_cr; the thermal part is empty, quirk C4), on the
     device (K5), then photon_synch's conversion to fluxes at Earth (src/photon_synch.jl:74-108) with the luminosity distance
     of photon_calcs.jl:40.  The photon stack is dead code in the reference: followed as
-    specification.  Inverse Compton: `photon_ic` below; pion decay (nuclei): `photon_pion`."""
+    specification.  Inverse Compton: `photon_ic` below; pion decay (nuclei): `photon_pion`; the sum of the three: `summed_emission`."""
     P = prob.params
     sp = prob.cfg.species[i_ion - 1]
     if sp.aa >= 1:
@@ -328,6 +328,124 @@ def photon_pion(prob, backend, ion_fin: IonFinal, i_ion: int, jet_dist_kpc: floa
     psum = np.where(lit, eflux / E_erg[None, :], 0.0)
     pflux = np.where(eflux <= 1.0e-99, 1.0e-99, eflux / E_erg[None, :])
     return PhotonPion(E_erg / MEV_ERG, emis, eflux, pflux, psum, sum(1 for s in cfg.species if s.aa >= 1))
+
+
+# ---- get_summed_emission (src/get_summed_emission.jl:37-413): the arithmetic of it ------------------------------------------------------
+# The function is 834 lines of which 700 read the photon_*_grid.dat files back in and write histograms; its calculation is restated here
+# on the arrays the three emission routines above return: the plasma-frame spectra (pion decay, synchrotron) are Doppler-shifted into the
+# ISM frame, the zones are summed into the photon shells, and the three processes are laid onto one energy grid.  Dead code like the rest
+# of the photon stack, followed as specification; where it cannot run as written:
+#   S1  `log_energy_MeV_in` is overwritten with the LINEAR energies (:136, :141) and "dlogE" is then taken as the difference of two of them
+#       (:150): the logarithmic bin width 1 / bins_per_decade is used, as :258 does;
+#   S2  the three factors of the Lorentz factor (:188-198) are applied after the loop over the zones with the LAST zone's value: every zone
+#       gets its own;
+#   S3  `findnext` returns nothing for a photon shifted beyond the energy grid (:178-179): dropped;
+#   S4  `sum_synch_IC_spectra()` is not defined: synchrotron and inverse-Compton bins are ADDED to the total at their offsets, as the pion
+#       decay ones are assigned (:277);
+#   S6  a shell's sum over its zones adds their 1e-99 floors (:792: log10 then gives -97.5 for a shell of three dark zones): floors are not summed;
+#   S5  only the Doppler-shifted spectra are converted from photons per d(log E) to photons per bin (:166-170) while all three are divided by
+#       the bin width at the end (:281-312): the inverse-Compton spectrum is converted too.
+N_COS_BINS_DOPPLER = 180              # get_summed_emission.jl:117
+
+
+def photon_shells(prob, num_upstream_shells: int, num_downstream_shells: int):
+    """`set_photon_shells` (src/initializers.jl:305-398): shell boundaries between the shock and the free-escape boundaries, equal in
+    log10|x / rg0| from 0.1 rg0 outwards; and the grid zone each boundary falls in (src/MonteCarloScattering.jl:392-401).
+    -> (x_shell_endpoints_cm [n+1], n_shell_endpoints [n+1], 1-based zone numbers, 0 where no zone holds the boundary)."""
+    P, rg0 = prob.params, prob.rg0
+    nu, nd = int(num_upstream_shells), int(num_downstream_shells)
+    if nu < 1 or nd < 1:
+        raise ValueError("photon_shells: at least one shell on either side of the shock")
+    ends = np.zeros(nu + nd + 1)
+    w = (math.log10(abs(P.feb_upstream / rg0)) + 1) / nu
+    for i in range(1, nu + 1):
+        start = 0.0 if i == 1 else 10.0 ** (-1 + w * (i - 1))
+        n = nu + 1 - i
+        ends[n - 1] = -(10.0 ** (-1 + w * i)); ends[n] = -start
+    use_prp = not P.feb_downstream > 0
+    limit = P.x_grid_stop / rg0 if use_prp else P.feb_downstream / rg0
+    w = (math.log10(limit) + 1) / nd
+    for i in range(1, nd + 1):
+        ends[nu + i - 1] = 0.0 if i == 1 else 10.0 ** (-1 + w * (i - 1))
+        ends[nu + i] = 10.0 ** (-1 + w * i)
+    ends *= rg0
+    x = np.asarray(prob.x_grid_cm)
+    zones = np.zeros(nu + nd + 1, dtype=np.int64)
+    k = 0
+    for i in range(1, P.n_grid + 1):
+        if k <= nu + nd and x[i] <= ends[k] and x[i + 1] > ends[k]:
+            zones[k] = i
+            k += 1
+    return ends, zones
+
+
+def doppler_to_ism(flux, energy_MeV, gam_ef, beta_ef, bins_per_dec=PHOTON_BINS_PER_DEC):
+    """get_summed_emission.jl:103-200 for one emission process: photons per d(log10 E) emitted isotropically in the plasma frame of every zone,
+    re-binned by the Doppler-shifted energy of the central ray of 180 slices in cos(theta) (boundary 0 points upstream, towards the observer:
+    E' = E gamma sqrt((1 - beta c_l)(1 - beta c_l+1))) and multiplied by gamma^3.  flux [n_zone][n] (floor 1e-99) -> photons per BIN [n_zone][n]."""
+    flux = np.asarray(flux, dtype=np.float64); E = np.asarray(energy_MeV, dtype=np.float64)
+    nz, n = flux.shape
+    dlog = 1.0 / bins_per_dec                                                 # S1
+    mid = np.empty(n)
+    mid[:-1] = np.sqrt(E[:-1] * E[1:]); mid[-1] = mid[-2] * 10.0 ** dlog      # :151-155
+    cos_e = np.linspace(-1.0, 1.0, N_COS_BINS_DOPPLER + 1)
+    out = np.full((nz, n), 1.0e-99)
+    for i in range(nz):
+        num = np.where(flux[i] > 1.0e-90, flux[i] * dlog, flux[i]) / N_COS_BINS_DOPPLER        # :166-170, :179
+        fac = gam_ef[i] * np.sqrt((1 - beta_ef[i] * cos_e[:-1]) * (1 - beta_ef[i] * cos_e[1:]))     # [l]
+        Et = mid[None, :] * fac[:, None]                                                            # [l][j]
+        # findnext(>=(E'), E, 2) - 1 with the 1-based E[1..n]: the first index m >= 2 with E[m] >= E' (S3: none -> dropped)
+        m = np.searchsorted(E, Et, side="left")                  # 0-based index of the first E >= E'
+        m = np.maximum(m, 1)                                     # (the search starts at the second entry)
+        ok = (num[None, :] > 1.0e-99) & (m < n)
+        np.add.at(out[i], (m - 1)[ok], np.broadcast_to(num[None, :], Et.shape)[ok])
+        lit = out[i] > 1.0e-95
+        out[i] = np.where(lit, out[i] * gam_ef[i] ** 3, 1.0e-99)                                    # :188-198 (S2)
+    return out
+
+
+@dataclasses.dataclass
+class SummedEmission:
+    """What `get_summed_emission` writes to photon_*_summed.dat, photon_tot_summed.dat and photon_tot.dat."""
+    log_energy_MeV: np.ndarray        # [n_pts]  the common grid: 1e-13 MeV .. 1e12 MeV, 10 per decade
+    per_process: dict                 # name -> (log10 E [n], log10 photons / (cm^2 s) per d(log10 E) [n_shell][n], -99 = none)
+    per_shell: np.ndarray             # [n_shell][n_pts]  all processes, same units, -99 = none
+    total: np.ndarray                 # [n_pts]
+
+
+def summed_emission(prob, n_shell_endpoints, pion: PhotonPion = None, synch: PhotonSynch = None, ic: PhotonIC = None) -> SummedEmission:
+    """The arithmetic of `get_summed_emission` (src/get_summed_emission.jl:37-413) on the per-zone photon fluxes of `photon_pion`,
+    `photon_synch` and `photon_ic`: Doppler shift of the plasma-frame spectra, sum over the zones of every photon shell, one energy grid."""
+    P = prob.params
+    ends = np.asarray(n_shell_endpoints, dtype=np.int64)
+    n_shells = len(ends) - 1
+    gam_ef, beta_ef = np.asarray(prob.gam_ef)[1:P.n_grid + 1], np.asarray(prob.beta_ef)[1:P.n_grid + 1]
+    dlog = 1.0 / PHOTON_BINS_PER_DEC
+    n_pts = int((math.log10(PHOTON_E_MAX_MEV) - math.log10(PHOTON_E_MIN_MEV)) * PHOTON_BINS_PER_DEC)
+    grid = math.log10(PHOTON_E_MIN_MEV) + dlog * np.arange(n_pts)
+    total = np.full((n_shells, n_pts + 1), 1.0e-99)
+    per = {}
+    for name, ph, e_min, shift in (("pion", pion, PHOTON_PION_E_MIN_MEV, True), ("synch", synch, PHOTON_E_MIN_MEV, True), ("ic", ic, PHOTON_IC_E_MIN_MEV, False)):
+        if ph is None:
+            continue
+        E = np.asarray(ph.energy_MeV)[:-1]                       # "the subroutines don't write out the final value of each spectrum" (:457-466)
+        f = np.asarray(ph.photon_flux)[:, :-1]
+        if shift:
+            nb = doppler_to_ism(f, E, gam_ef, beta_ef)
+        else:
+            nb = np.where(f > 1.0e-90, f * dlog, f)              # (inverse Compton is computed in the ISM frame: number per bin only)
+        sh = np.full((n_shells, len(E)), 1.0e-99)
+        for n in range(n_shells):                                # sum_spectral_regions (:788-797)
+            lo, hi = int(ends[n]), int(ends[n + 1]) - 1
+            if lo >= 1 and hi >= lo:
+                sh[n] = np.maximum(np.where(nb[lo - 1:hi] > 1.0e-95, nb[lo - 1:hi], 0.0).sum(axis=0), 1.0e-99)     # (S6)
+        start = int(math.log10(e_min / PHOTON_E_MIN_MEV) * PHOTON_BINS_PER_DEC)      # :263-265
+        total[:, start + 1:start + 1 + len(E)] += np.where(sh > 1.0e-99, sh, 0.0)    # :277, S4
+        per[name] = (np.log10(E), np.where(sh > 1.0e-99, np.log10(np.maximum(sh, 1e-300) / dlog), -99.0))
+    tot_sh = total[:, 1:n_pts + 1]                                # (the total's index n_start + j is 1-based)
+    tot_all = tot_sh.sum(axis=0)
+    back = lambda a: np.where(a > 1.0e-96, np.log10(np.maximum(a, 1e-300) / dlog), -99.0)       # :297-312
+    return SummedEmission(grid, per, back(tot_sh), back(tot_all))
 
 
 def _takes_download(backend) -> bool:
