@@ -153,7 +153,8 @@ def workload_label(args):
 
 KERNEL_NAMES = {0: "mcs_k_transport", 1: "mcs_k_transport_plain", 2: "mcs_k_transport_lossy", 3: "mcs_k_transport_f32", 4: "mcs_k_transport_f32_loop",
                 5: "mcs_k_transport_f32_lossy", 6: "mcs_k_transport_plain_etf", 7: "mcs_k_transport_ws", 8: "mcs_k_transport_ws_etf",
-                9: "mcs_k_transport_f32_loop_exact", 10: "mcs_k_transport_sliced"}
+                9: "mcs_k_transport_f32_loop_exact", 10: "mcs_k_transport_sliced", 11: "mcs_k_transport_plain_sliced", 12: "mcs_k_transport_lossy_sliced",
+                13: "mcs_k_transport_plain_etf_sliced"}
 
 
 def kernel_label(args, last_kernel=None):
@@ -223,7 +224,7 @@ def main():
     # (room in the per-iteration tallies for the iterations of the extra overlapped leg, which carry on the numbering)
     overlap_leg = world == 1 and not force_comm and args.overlap > 1 and not args.smooth and not args.mixed and not args.fp32
     n_extra = (2 * args.overlap + args.steps) if overlap_leg else 0
-    pipe_leg = world == 1 and not force_comm and args.long_draws > 0 and not args.mixed and not args.fp32 and not args.smooth
+    pipe_leg = world == 1 and not force_comm and args.long_draws > 0 and not args.fp32 and not args.smooth
     pipe_first = n_itrs + n_extra + 1
     if pipe_leg:
         n_extra += 1 + args.steps

@@ -390,7 +390,8 @@ int mcs_set_launch(mcs_ctx* ctx, int blocks, int threads);
  * mcs_last_kernel: which transport kernel they ran -- 0 the general kernel, 1 its specialisation for the common configuration,
  * 2 the one for electrons with radiative losses, 3 the fp32-state kernel, 4 its plain-loop form, 5 its specialisation for
  * electrons with radiative losses, 6 the common configuration with ion -> electron energy transfer on.  * 7 / 8: the wave-specialised kernel for the common configuration / the same with energy transfer (MCS_K1_WS=1), 9: the fp32-state
- * plain loop with the exact primitives (MCS_F32_EXACT=1), 10: the general kernel's form for sliced launches. */
+ * plain loop with the exact primitives (MCS_F32_EXACT=1), 10: the general kernel's form for sliced launches, 11 / 12 / 13: the sliced forms
+ * of 1 / 2 / 6 (what mcs_run_pcuts_pipelined launches). */
 int mcs_set_tail_slicing(mcs_ctx* ctx, int budget_trips);
 /* A species' pcuts first .. last queued back to back: transport, pcut_finalize and new_pcut (src/cuts.jl:34-124) of every pcut with
  * nothing read back in between -- n_saved, i_mult = max(n_target / n_saved, 1) (src/cuts.jl:42) and the size of the next population

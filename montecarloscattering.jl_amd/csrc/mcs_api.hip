@@ -1049,7 +1049,8 @@ int mcs_run_pcuts_pipelined(mcs_ctx* c, int i_pcut_first, int i_pcut_last, const
     KArgs t; fill_kargs(c, t, i_pcut_first, 0, 0, 1, nullptr, 0);
     int kk = species_kernel_kind(c, t, 0, nullptr);
     if (kk == 7) kk = 1;
-    kind = kk == 1 ? 11 : 10;          // the sliced form of the PLAIN kernel, else of the general one
+    if (kk == 8) kk = 6;
+    kind = kk == 1 ? 11 : (kk == 2 ? 12 : (kk == 6 ? 13 : 10));      // the sliced form of the species' kernel: PLAIN, LOSSY, PLAIN_ETF, general
   }
   PopBuf cur = c->cur, nxt = c->spare;
   PopBuf savb[2] = {c->sav, c->pp_sav2};

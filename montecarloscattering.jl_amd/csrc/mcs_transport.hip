@@ -2305,6 +2305,13 @@ extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_tran
 extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain_sliced(const KArgs* __restrict__ ka) {
   transport_body<true, false, false, true>(ka);
 }
+// ... and of the two other specialisations (electrons with radiative losses; ions with energy transfer): the species mix of BASELINE config[4]
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_lossy_sliced(const KArgs* __restrict__ ka) {
+  transport_body<false, true, false, true>(ka);
+}
+extern "C" __global__ void __launch_bounds__(256, MCS_WAVES_PER_SIMD) mcs_k_transport_plain_etf_sliced(const KArgs* __restrict__ ka) {
+  transport_body<true, false, true, true>(ka);
+}
 
 #ifdef MCS_PROF
 extern "C" int mcs_prof_waves(unsigned long long* out) {
@@ -2330,6 +2337,8 @@ extern "C" hipError_t mcs_launch_transport(const KArgs* a_dev, int kind, int blo
   else if (kind == 6) hipLaunchKernelGGL(mcs_k_transport_plain_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 10) hipLaunchKernelGGL(mcs_k_transport_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 11) hipLaunchKernelGGL(mcs_k_transport_plain_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 12) hipLaunchKernelGGL(mcs_k_transport_lossy_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
+  else if (kind == 13) hipLaunchKernelGGL(mcs_k_transport_plain_etf_sliced, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 7) hipLaunchKernelGGL(mcs_k_transport_ws, dim3(blocks), dim3(threads), 0, st, a_dev);
   else if (kind == 8) hipLaunchKernelGGL(mcs_k_transport_ws_etf, dim3(blocks), dim3(threads), 0, st, a_dev);
   else hipLaunchKernelGGL(mcs_k_transport, dim3(blocks), dim3(threads), 0, st, a_dev);

@@ -104,7 +104,8 @@ class HipBackend:
         return int(self.lib.mcs_last_launches(self.h))
 
     def last_kernel(self) -> int:
-        """0 general, 1 plain, 2 lossy, 3 fp32, 4 fp32 plain loop, 5 fp32 lossy, 6 plain with energy transfer (mcs_last_kernel)"""
+        """0 general, 1 plain, 2 lossy, 3 fp32, 4 fp32 plain loop, 5 fp32 lossy, 6 plain with energy transfer, 7 / 8 wave-specialised, 9 fp32 exact loop,
+        10 general sliced, 11 / 12 / 13 the sliced forms of 1 / 2 / 6 (mcs_last_kernel)"""
         return int(self.lib.mcs_last_kernel(self.h))
 
     # -- per iteration / species

@@ -114,6 +114,29 @@ def test_gpu_pipelined_loop_equals_the_oracle_in_the_same_order(N, B, imax):
 
 
 @pytest.mark.gpu
+def test_gpu_pipelined_loop_species_mix_with_energy_transfer_and_losses():
+    """BASELINE config[4]'s species mix (p + He + e-, ion -> electron energy transfer, radiative losses): the sliced forms of the PLAIN_ETF
+    and LOSSY kernels (kinds 13 and 12), every species against the oracle in the same population order"""
+    from conftest import hip_backend
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    sp = [mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.2)]
+    prob = make_problem(4000, species=sp, energy_transfer_frac=0.1, radiation_losses=True)
+    ob = oracle_backend(prob, nthreads=16)
+    ro = mcs.driver.run(prob, ob, n_itrs=1, long_draws=1500, long_imult_max=8)
+    hb = hip_backend(prob)
+    kinds = []
+    rg = mcs.driver.run(prob, hb, n_itrs=1, long_draws=1500, long_imult_max=8, on_species_end=lambda *a: kinds.append(hb.last_kernel()))
+    assert kinds == [13, 13, 12]
+    assert _stats(ro) == _stats(rg)
+    assert np.array_equal(ro.tallies_i64, rg.tallies_i64)
+    assert_tallies_close(mcs.capi.Layout(prob.params), ro.tallies_f64, rg.tallies_f64, rtol=1e-11)
+    for (ia, ja, fa, ka), (ib, jb, fb, kb) in zip(ro.per_species, rg.per_species):
+        assert (ia, ja) == (ib, jb) and np.array_equal(ka, kb)
+        assert_tallies_close(mcs.capi.Layout(prob.params), fa, fb, rtol=1e-11)
+    ob.destroy(); hb.destroy()
+
+
+@pytest.mark.gpu
 def test_gpu_pipelined_loop_over_iterations_and_tiny_populations():
     """two iterations on one context (buffers, streams and counters are reused), and populations smaller than a workgroup"""
     from conftest import hip_backend
