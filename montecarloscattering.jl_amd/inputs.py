@@ -507,9 +507,37 @@ def build_problem(cfg: Config) -> Problem:
     uz = np.zeros(ne)
     utot = ux.copy()
     theta = np.full(ne, math.radians(cfg.theta_B0))
+    eps_B = np.full(ne, 1.0e-99)                                   # initializers.jl:847
     if cfg.use_custom_epsB:
-        raise NotImplementedError("set_custom_εB! (initializers.jl:868-930) is a profile initialiser outside the "
-                                  "transport path; pass btot tables explicitly and set params.use_custom_epsB")
+        # set_custom_εB! (initializers.jl:868-951) and the field it implies (:833-845): epsilon_B against the distance from the shock in
+        # plasma skin depths -- a rising power law far upstream, a plateau of 1e-4 within 50 skin depths, a 1/x decay downstream -- and
+        # B = sqrt(|8 pi epsilon_B e(x)|) with e(x) = (F_en0 + gam0 u0 e0) / u(x) - F_px0.
+        #   E1  `comp_fac` is 0.0 when the function is called: the loop above assigns a `local comp_fac` (:791, :815), so epsilon_B2 = 0,
+        #       the decay never ends (5e-3 / 0 = Inf) and the last branch (:945) is never taken.  As written.
+        from types import SimpleNamespace
+        from .iter_finalize import upstream_fluxes
+        F_px, _, F_en = upstream_fluxes(SimpleNamespace(params=SimpleNamespace(u0=u0, beta0=beta0, gam0=gam0), cfg=cfg))
+        n0_tot = sum(s.density * s.mass for s in species) / MP
+        e0 = n0_tot * MP * C * C
+        eps_B0 = B0 ** 2 / (8 * math.pi * e0)
+        n0_electron = species[-1].density                          # "electron number density": the LAST species, whatever it is (:899)
+        sigma = 2 * eps_B0 / gam0
+        rg2sd = beta0 / math.sqrt(sigma * n0_tot / n0_electron)
+        comp_fac_call = 0.0                                        # E1
+        e_dens2 = (F_en + gam0 * u0 * e0) / ux[-1] - F_px
+        eps_B2 = (B0 * comp_fac_call) ** 2 / (8 * math.pi * e_dens2)
+        end_decay_rg = math.inf if eps_B2 == 0 else (5.0e-3 / eps_B2) / rg2sd
+        for i in range(ne):
+            x_sd = x_grid_rg[i] * rg2sd
+            if x_sd < -50:
+                eps_B[i] = max(1.04e-5 / abs(x_sd) ** 0.6, eps_B0)
+            elif x_sd < 50:
+                eps_B[i] = 1.0e-4
+            elif x_grid_rg[i] < end_decay_rg:
+                eps_B[i] = 5.0e-3 / x_sd
+            else:
+                eps_B[i] = eps_B2
+            bt[i] = math.sqrt(abs(8 * math.pi * eps_B[i] * ((F_en + gam0 * u0 * e0) / ux[i] - F_px)))
     bmag2 = float(bt[-1])
 
     i_shock = int(np.nonzero(x_grid_rg <= 0)[0][-1])              # MonteCarloScattering.jl:478

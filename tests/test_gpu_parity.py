@@ -971,16 +971,17 @@ def test_config0_stock_input_shape_vs_oracle():
     no-scatter = true and no-DSA = true (the committed file is a scatter-free plumbing run, /root/reference/mc_in.toml:136,139),
     radiative losses, energy-transfer-frac 0.1, compressed turbulence in the field, the custom-eps_B flag, the stock time and
     momentum cuts -- on the GPU and on the oracle through the same driver; integers, populations and binned tallies must
-    agree as in every other whole-iteration test.  Two things of the stock file cannot be taken literally: DENZ_ION = [1, 0]
-    gives the electrons zero weight and electron_weight_fac = 1/0 (quirk G4: n_e = n_p is used), and the custom-eps_B
-    PROFILE comes from an initialiser outside the path (the flag is set on the compressed-turbulence tables)."""
+    agree as in every other whole-iteration test.  One thing of the stock file cannot be taken literally: DENZ_ION = [1, 0]
+    gives the electrons zero weight and electron_weight_fac = 1/0 (quirk G4: n_e = n_p is used).  Round 4: the custom-eps_B
+    PROFILE comes from the reference's initialiser (`set_custom_εB!`, restated in inputs.build_problem), no longer from the flag
+    set on the compressed-turbulence tables."""
     N = 10_000
     me_mp = mcs.constants.ME / mcs.constants.MP
     kw = dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.0)],
               no_scatter=True, no_DSA=True, radiation_losses=True, energy_transfer_frac=0.1, b_field_turbulence=1.0,
-              b_field_amplify=1.0, electron_energy_mfp_threshold=1e4)
+              b_field_amplify=1.0, electron_energy_mfp_threshold=1e4, use_custom_epsB=True)
     pg, po = make_problem(N, **kw), make_problem(N, **kw)
-    pg.params.use_custom_epsB = 1; po.params.use_custom_epsB = 1
+    assert pg.params.use_custom_epsB == 1 and np.ptp(pg.btot[1:pg.n_grid + 1]) > 0       # the field of the eps_B profile, not a constant
     hb, ob = hip_backend(pg), oracle_backend(po, nthreads=16)
     rg = mcs.driver.run(pg, hb, None, n_itrs=1, finalize=True)
     ro = mcs.driver.run(po, ob, None, n_itrs=1, finalize=True)

@@ -76,3 +76,35 @@ def test_shard_ranges():
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         sizes = [b - a for a, b in r]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_custom_epsB_profile():
+    """`set_custom_εB!` (src/initializers.jl:868-951) and the field it implies (:833-845), restated in build_problem: epsilon_B against
+    the distance from the shock in plasma skin depths, B = sqrt(|8 pi epsilon_B e(x)|)."""
+    import math
+    me_mp = mcs.constants.ME / mcs.constants.MP
+    C, MP = mcs.constants.C, mcs.constants.MP
+    sp = [mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(me_mp, -1.0, 1e6, 1.0)]
+    plain = make_problem(16, species=sp)
+    prob = make_problem(16, species=sp, use_custom_epsB=True)
+    assert prob.params.use_custom_epsB == 1 and plain.params.use_custom_epsB == 0
+    P, cfg = prob.params, prob.cfg
+    F_px, _, F_en = mcs.iter_finalize.upstream_fluxes(prob)
+    n0 = sum(s.density * s.mass for s in sp) / MP
+    e0 = n0 * MP * C * C
+    eps0 = cfg.B_mag_upstream ** 2 / (8 * math.pi * e0)
+    rg2sd = P.beta0 / math.sqrt(2 * eps0 / P.gam0 * n0 / sp[-1].density)
+    x_sd = np.asarray(prob.x_grid_rg) * rg2sd
+    e_x = (F_en + P.gam0 * P.u0 * e0) / np.asarray(prob.ux) - F_px
+    eps = np.asarray(prob.btot) ** 2 / (8 * math.pi * np.abs(e_x))
+    far_up, near, down = x_sd < -50, np.abs(x_sd) < 50, x_sd >= 50
+    assert far_up.any() and near.any() and down.any()
+    assert np.allclose(eps[far_up], np.maximum(1.04e-5 / np.abs(x_sd[far_up]) ** 0.6, eps0), rtol=1e-12)
+    assert np.allclose(eps[near], 1.0e-4, rtol=1e-12)
+    assert np.allclose(eps[down], 5.0e-3 / x_sd[down], rtol=1e-12)          # E1: the decay never ends (comp_fac is 0 at the call)
+    # far upstream epsilon_B falls to its floor B0^2 / (8 pi e0) and the field is the upstream field again (cold plasma: e(x) ~ e0)
+    assert abs(prob.btot[0] / cfg.B_mag_upstream - 1) < 1e-3
+    # everything but the field is the unmodified profile
+    for name in ("ux", "gam_sf", "gam_ef", "beta_ef", "theta"):
+        assert np.array_equal(getattr(prob, name), getattr(plain, name))
+    assert not np.array_equal(prob.btot, plain.btot)
