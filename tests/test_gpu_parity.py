@@ -210,6 +210,12 @@ def test_saved_export_and_split_import():
     hb.destroy(); hb2.destroy()
 
 
+def test_strided_init_and_indexed_run_wave_specialised_kernel(monkeypatch):
+    """the same entry points with the wave-specialised kernel forced: what config[3]'s 1.25e7 particles per GPU select (>= MCS_WS_AUTO_MIN)"""
+    monkeypatch.setenv("MCS_K1_WS", "1")
+    test_strided_init_and_indexed_run()
+
+
 def test_strided_init_and_indexed_run():
     """The multi-GPU entry points of round 2: mcs_init_pop_binned_strided deals the injection out (rank r of W holds
     global particles r, r + W, ...), mcs_run_pcut_indexed runs a shard whose global indices are an arbitrary list,
