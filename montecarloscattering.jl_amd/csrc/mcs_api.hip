@@ -113,6 +113,7 @@ struct mcs_ctx {
                                // oracle/mcs_oracle_f32.inc reproduces bit for bit (tests)
   bool f32_loop = false;       // MCS_F32_LOOP=1: the fp32-state variant as a plain per-lane loop (the reference semantics of that variant; tests)
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
+  int tail_loop = 8;           // MCS_TAIL_LOOP=<n>: live lanes at or below which an exhausted wave runs the tight tail loop (0 = off; needs the tail ring)
   int refill_min = 12;         // MCS_REFILL_MIN=<n> (environment) overrides: A/B measurements
   int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
   // finals
@@ -324,6 +325,7 @@ int mcs_create(const mcs_params* p, int device, void* stream, mcs_ctx** out) {
   { const char* e = std::getenv("MCS_WS_SERVE"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 64) c->ws_serve_min = std::atoi(e); }
   { const char* e = std::getenv("MCS_PARK"); c->park = !(e && e[0] == '0'); }
   { const char* e = std::getenv("MCS_TAIL_RING"); c->tail_ring = !(e && e[0] == '0'); }
+  { const char* e = std::getenv("MCS_TAIL_LOOP"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 32) c->tail_loop = std::atoi(e); }
   { const char* e = std::getenv("MCS_F32_LOOP"); c->f32_loop = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_F32_EXACT"); c->f32_exact = e && e[0] == '1'; }
   { const char* e = std::getenv("MCS_F32_BLOCKS"); if (e && std::atoi(e) >= 1 && std::atoi(e) <= 8) c->f32_blocks_per_cu = std::atoi(e); }
@@ -710,6 +712,7 @@ static void fill_kargs(mcs_ctx* c, KArgs& a, int i_pcut, long long n, long long 
   // defer_k + refill_min <= 64 either defer_k lanes are live or refill_min are idle (see the deferral in transport_body)
   if (a.defer_k > 64 - a.refill_min) a.defer_k = 64 - a.refill_min;
   a.tail_ring = c->tail_ring ? 1 : 0;
+  a.tail_loop = c->tail_ring ? c->tail_loop : 0;
   // iseed_mod - i_prt, src/particle_loop.jl:35-40
   a.seed_base = (unsigned long long)((long long)(c->i_iter - 1) * c->P.n_pts_max * c->tb.n_pcuts * c->P.n_ions +
                                      (long long)(c->i_ion - 1) * c->P.n_pts_max * c->tb.n_pcuts +

@@ -78,6 +78,10 @@ struct KArgs {
   // reached long_draws (so everything exported is long; `budget_trips` only has to be non-zero), and every particle's status byte carries
   // the verdict: l_save = 1 saved, 2 ended, + 4 when long.  0: off.
   unsigned int long_draws;
+  // ---- tail loop (round 4; transport_body "tail loop"): once the queue is exhausted, a wave with at most `tail_loop` live particles runs
+  // its common passes in a tight loop of their own -- one pass per trip of THAT loop, the draw-dependent half from the tail ring, no
+  // housekeeping, no six-pass bookkeeping -- until some live lane has an event or the ring batch is used up.  0: off (MCS_TAIL_LOOP=0).
+  int tail_loop;
 };
 
 // Replicas of the tally buffer.  Particles of one population pile their tallies onto

@@ -1769,6 +1769,35 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
   unsigned ringD = 1u;              // wave-uniform: entries per live lane in the current batch
   unsigned defer_k = h.every_pass ? 1u : (unsigned)__builtin_amdgcn_readfirstlane(a->defer_k);      // 1 once the work counter is exhausted
   p.npush = 0;
+  // a new ring batch for every live particle (am: the live lanes, L of them): owners publish (key, draw index) by rank, workers evaluate
+  // D = floor(64 / L) draws ahead per live particle (any D, not just powers of two: L = 10 gets 6, not 4);
+  // lane -> (particle q, draw jw) by a multiply and a shift: floor(lane / D) == (lane * M) >> 16 with
+  // M = floor(65536 / D) + 1 for every lane < 64 and D <= 64
+  auto build_batch = [&](const unsigned long long am, const unsigned L) {
+    const unsigned D = 64u / L;
+    const unsigned M = 65536u / D + 1u;
+    const unsigned rank = below(am);
+    if (active) {
+      S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
+      S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
+      S_evf[wv][5][128u + rank] = 1 - p.cm_val;      // the owner's 1 - cos_max: the cone of the deflection is part of the batch
+    }
+    const unsigned q = (lane * M) >> 16, jw = lane - q * D;
+    const bool valid = q < L;
+    const unsigned qq = valid ? q : 0u;
+    const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq], womc = S_evf[wv][5][128u + qq];
+    double eU1, es, ec, ecd, esd, essd;
+    scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
+    scatter_cone(eU1, es, womc, ecd, esd, essd);
+    if (valid) {       // entry q * D + jw == lane
+      S_evf[wv][0][128u + lane] = ecd; S_evf[wv][1][128u + lane] = esd; S_evf[wv][2][128u + lane] = ec; S_evf[wv][6][128u + lane] = essd;
+    }
+    if (active) { rb = rng.n; rrow = rank * D; }
+    ringD = D;
+  };
+  // (see KArgs::tail_loop)
+  constexpr bool TAIL_LOOP = PLAIN && !LOSSY && !PLAIN_ETF && !SLICED;      // (the kernels that carry the loop: see the resource limits in tools/check_resources.py)
+  const unsigned tail_loop_L = TAIL_LOOP ? (unsigned)__builtin_amdgcn_readfirstlane(a->tail_loop) : 0u;
   bool done = false;
   while (!done) {
     ev_pending += (unsigned)(__popcll(__builtin_amdgcn_ballot_w64(p.npush > 0)) + __popcll(__builtin_amdgcn_ballot_w64(p.npush > 1)));
@@ -2147,6 +2176,55 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     // in a pass)
     const bool may_go_on = (p.flags == 0) & !h.every_pass;
     bool stopped = false;
+    // ---- tail loop.  After the queue is exhausted the launch waits for its longest histories, a few lanes per wave at the end and
+    // finally ONE particle alone on its SIMD for thousands of passes (the helix cap allows 10^4), and an instruction costs a wave
+    // the same with one lane enabled as with 64: what counts is the number of instructions between two passes of that particle.
+    // A wave with at most tail_loop_L live particles therefore leaves the six-pass trip (header, housekeeping test, want / enter
+    // logic, per-pass ring test, lane-mask arithmetic: ~120 instructions and ~8 branches per pass of overhead beside the ~95 of
+    // the state-dependent half of a pass) and runs the passes in a loop of their own: the draw-dependent half from the tail ring,
+    // the state-dependent half (scattering_rest, clock, move, thresholds), ONE exit test.  It leaves the loop when a live lane
+    // has an event or a flag (the rare region is due), or has used its ring entries up (the next trip builds a new batch).
+    // Same statements on the same values in the same order for every particle: results are unchanged.
+    bool tail_fast = false;
+    unsigned long long am_t = 0ull;
+    if constexpr (TAIL_LOOP) {
+      if (MCS_UNLIKELY(ring_on)) {
+        am_t = __builtin_amdgcn_ballot_w64(active);
+        // (at least one live lane, and every live lane runs -- nothing is frozen or waits once the queue is exhausted)
+        tail_fast = (Lh <= tail_loop_L) & (am_t != 0ull) & (__builtin_amdgcn_ballot_w64(active & !run) == 0ull);
+      }
+    }
+    if (MCS_UNLIKELY(tail_fast)) {
+      // (every lane computes, the idle ones on whatever state they hold -- as in the common pass of the bulk, nothing of it is stored --:
+      // no exec-mask region in the loop; it runs while EVERY live lane goes on)
+      unsigned jj = (rng.n - rb) >> 1;
+      if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
+        build_batch(am_t, (unsigned)__popcll(am_t));
+        jj = 0u;
+      }
+      unsigned e = (rrow + jj) & 63u;
+      const unsigned long long m_halt = __builtin_amdgcn_ballot_w64(!may_go_on);      // (flags do not change in a pass)
+#pragma nounroll
+      for (;;) {
+        PROF_LANES(9, active); PROF_ADD(7, 1);
+        p.helix += 1;
+        if (!h.dont_scatter) {
+          rng.n += 2u;
+          const double cos_d = S_evf[wv][0][128u + e], sin_d = S_evf[wv][1][128u + e], c_ps = S_evf[wv][2][128u + e], ssd = S_evf[wv][6][128u + e];
+          scattering_rest(p, kc, cos_d, sin_d, c_ps, ssd);
+        }
+        p.acctime = p.acctime + t_clock * p.c_gef;
+        p.n_ovr += (unsigned)p.ovr_inc;
+        const bool ev_time = p.acctime >= p.c_tev;
+        bool x1;
+        const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1, true) | ev_time | (p.helix >= MCS_HELIX_CAP);
+        evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
+        e = (e + 1u) & 63u; jj += 1u;
+        t_clock = p.t_step;
+        const unsigned long long m_stop = __builtin_amdgcn_ballot_w64(e1 | x1 | (jj >= ringD)) | m_halt;
+        if ((m_stop & am_t) != 0ull) break;
+      }
+    } else
 #pragma unroll
     for (int rep = 0; rep < MCS_PASSES_PER_ITER; ++rep) {
       if (rep > 0) {
@@ -2164,30 +2242,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if ((L >= 1u) & (Lh <= 32u)) {
           unsigned jj = (rng.n - rb) >> 1;
           if (__builtin_amdgcn_ballot_w64(active && jj >= ringD) != 0ull) {
-            // a new batch for every live particle: owners publish (key, draw index) by rank, workers evaluate
-            // D = floor(64 / L) draws ahead per live particle (any D, not just powers of two: L = 10 gets 6, not 4);
-            // lane -> (particle q, draw jw) by a multiply and a shift: floor(lane / D) == (lane * M) >> 16 with
-            // M = floor(65536 / D) + 1 for every lane < 64 and D <= 64
-            const unsigned D = 64u / L;
-            const unsigned M = 65536u / D + 1u;
-            const unsigned rank = below(am);
-            if (active) {
-              S_evf[wv][3][128u + rank] = __hiloint2double((int)rng.k0, (int)rng.k1);
-              S_evf[wv][4][128u + rank] = __hiloint2double((int)rng.n, 0);
-              S_evf[wv][5][128u + rank] = 1 - p.cm_val;      // the owner's 1 - cos_max: the cone of the deflection is part of the batch
-            }
-            const unsigned q = (lane * M) >> 16, jw = lane - q * D;
-            const bool valid = q < L;
-            const unsigned qq = valid ? q : 0u;
-            const double w1 = S_evf[wv][3][128u + qq], w2 = S_evf[wv][4][128u + qq], womc = S_evf[wv][5][128u + qq];
-            double eU1, es, ec, ecd, esd, essd;
-            scatter_draws((uint32_t)__double2hiint(w1), (uint32_t)__double2loint(w1), ((uint32_t)__double2hiint(w2) >> 1) + jw, kc, eU1, es, ec);
-            scatter_cone(eU1, es, womc, ecd, esd, essd);
-            if (valid) {       // entry q * D + jw == lane
-              S_evf[wv][0][128u + lane] = ecd; S_evf[wv][1][128u + lane] = esd; S_evf[wv][2][128u + lane] = ec; S_evf[wv][6][128u + lane] = essd;
-            }
-            if (active) { rb = rng.n; rrow = rank * D; }
-            ringD = D;
+            build_batch(am, L);
             jj = 0u;
           }
           ridx = (rrow + jj) & 63u;
