@@ -1796,7 +1796,7 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
     ringD = D;
   };
   // (see KArgs::tail_loop)
-  constexpr bool TAIL_LOOP = PLAIN && !LOSSY && !PLAIN_ETF && !SLICED;      // (the kernels that carry the loop: see the resource limits in tools/check_resources.py)
+  constexpr bool TAIL_LOOP = !LOSSY;      // (LOSSY: no tail ring -- the cone changes in every pass)
   const unsigned tail_loop_L = TAIL_LOOP ? (unsigned)__builtin_amdgcn_readfirstlane(a->tail_loop) : 0u;
   bool done = false;
   while (!done) {
