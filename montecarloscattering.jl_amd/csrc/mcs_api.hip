@@ -113,7 +113,7 @@ struct mcs_ctx {
                                // oracle/mcs_oracle_f32.inc reproduces bit for bit (tests)
   bool f32_loop = false;       // MCS_F32_LOOP=1: the fp32-state variant as a plain per-lane loop (the reference semantics of that variant; tests)
   bool tail_ring = true;       // MCS_TAIL_RING=0: no precomputed scatter draws in the tail (A/B measurements)
-  int tail_loop = 8;           // MCS_TAIL_LOOP=<n>: live lanes at or below which an exhausted wave runs the tight tail loop (0 = off; needs the tail ring)
+  int tail_loop = 12;          // MCS_TAIL_LOOP=<n>: live lanes at or below which an exhausted wave runs the tight tail loop (0 = off; needs the tail ring)
   int refill_min = 12;         // MCS_REFILL_MIN=<n> (environment) overrides: A/B measurements
   int defer_k = 8;             // MCS_DEFER_K=<n> (environment) overrides: A/B measurements, 1 = no deferral
   // finals
