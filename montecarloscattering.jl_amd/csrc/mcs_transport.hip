@@ -484,6 +484,61 @@ __device__ __forceinline__ void scattering_with(Pt& p, const mcsm::HotCoef& kc, 
   scatter_cone(U1, s_ps, 1 - p.cm_val, cos_d, sin_d, ssd);
   scattering_rest(p, kc, cos_d, sin_d, c_ps, ssd);
 }
+// ---- the state-dependent half of a pass with its 64-bit literals handed in (tail loop).  The build keeps literals out of registers
+// (MCS_SC, -disable-machine-licm: each is rematerialised by two s_mov where it is used), which is right for the bulk of a launch --
+// scalar instructions issue beside the other wave's vector ones -- and wrong for a wave alone on its SIMD, where every instruction
+// costs an issue slot: 16 s_mov per pass.  The tail loop pins the seven values in scalar registers before its first pass (sconst)
+// and runs these forms: the statements of sqrt_nn_, asin_t, mod2pi (include/mcs_math.h) and scattering_rest, operand for operand.
+struct TailK { double halfpi, pio2_lo, twopi, twopi_lo, inv_twopi, sin_ul, dmin; };
+__device__ __forceinline__ double sqrt_nn_k(double x, const TailK& K) {
+  const double y = __builtin_amdgcn_rsq(__builtin_fmax(x, K.dmin));
+  double g = x * y;
+  double hh = 0.5 * y;
+  const double r = __builtin_fma(-hh, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  hh = __builtin_fma(hh, r, hh);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, hh, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, hh, g);
+  return g;
+}
+__device__ __forceinline__ double asin_tk(double x, const mcsm::HotCoef& k, const TailK& K) {
+  const double ax = __builtin_fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : (1.0 - ax) * 0.5;
+  const double sv = small ? ax : sqrt_nn_k(z, K);
+  double q = k.A12;
+  q = __builtin_fma(q, z, k.A11); q = __builtin_fma(q, z, k.A10); q = __builtin_fma(q, z, k.A9); q = __builtin_fma(q, z, k.A8); q = __builtin_fma(q, z, k.A7);
+  q = __builtin_fma(q, z, k.A6); q = __builtin_fma(q, z, k.A5); q = __builtin_fma(q, z, k.A4); q = __builtin_fma(q, z, k.A3); q = __builtin_fma(q, z, k.A2);
+  q = __builtin_fma(q, z, k.A1); q = __builtin_fma(q, z, k.A0);
+  const double t = __builtin_fma(sv * z, q, sv);
+  const double big = K.halfpi - (2.0 * t - K.pio2_lo);
+  return __builtin_copysign(small ? t : big, x);
+}
+__device__ __forceinline__ double mod2pi_k(double x, const TailK& K) {
+  const double k = __builtin_floor(x * K.inv_twopi);
+  double r = __builtin_fma(-k, K.twopi, x);
+  r = __builtin_fma(-k, K.twopi_lo, r);
+  r = r < 0.0 ? r + K.twopi : r;
+  r = r >= K.twopi ? r - K.twopi : r;
+  return r;
+}
+__device__ __forceinline__ void scattering_rest_k(Pt& p, const mcsm::HotCoef& kc, const TailK& K, double cos_d, double sin_d, double c_ps, double ssd) {
+  const double cos_old = div_r(p.pb_pf, p.ptot_pf, p.rp_val);
+  const double sin_old = div_r(p.p_perp, p.ptot_pf, p.rp_val);
+  const double cos_new = cos_old * cos_d + sin_old * sin_d * c_ps;
+  const double arg = __builtin_fmax(1 - cos_new * cos_new, 0.0);
+  const double sin_new = sqrt_nn_k(arg, K);
+  p.pb_pf = p.ptot_pf * cos_new;
+  p.p_perp = p.ptot_pf * sin_new;
+  const double phi_p_old = p.phi + K.halfpi;
+  double sd = fdiv(ssd, sin_new);
+  sd = __builtin_fmin(__builtin_fmax(sd, -K.sin_ul), K.sin_ul);
+  const double adj = asin_tk(sd, kc, K);
+  const double phi_p_new = sin_new != 0 ? phi_p_old + adj : phi_p_old;
+  p.phi = phi_p_new - K.halfpi;
+}
 // the two draws of a scatter are indices n, n+1 = one Philox block
 __device__ __forceinline__ void scattering(Rng& rng, Pt& p, const mcsm::HotCoef& kc) {
   double U1, s_ps, c_ps;
@@ -1091,13 +1146,15 @@ __device__ __forceinline__ void refresh_thr(const Hot& h, Pt& p) {
 
 // The common pass's version of move_and_detect: same move, the position events through the two thresholds.
 // Returns the events that are not position thresholds (odd configurations); ev_cross = some threshold reached.
-__device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross, const bool xn_is_threshold = true) {
+// (K: the tail loop's literals in registers, see TailK)
+__device__ __forceinline__ bool move_and_detect_thr(CK* a, const Hot& h, Pt& p, double& phi_old_out, bool& ev_cross, const bool xn_is_threshold = true,
+                                                    const TailK* K = nullptr) {
   const int ig3 = p.ig3;
   const double gsf = p.z_gsf, bcos = p.z_bcos, ux = p.z_ux;
   p.x_old = p.x;
   const double phi_old = p.phi;
   phi_old_out = phi_old;
-  p.phi = mcsm::mod2pi(p.phi + p.dphi);
+  p.phi = K ? mod2pi_k(p.phi + p.dphi, *K) : mcsm::mod2pi(p.phi + p.dphi);
   const double gm = p.gam_pf * h.m;
   const double x_move = div_r(p.pb_pf * p.t_step, gm, p.rg_val);   // == pb_pf * t_step / (gam_pf * m)
   double gyr = 0.0;
@@ -2204,6 +2261,9 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
       }
       unsigned e = (rrow + jj) & 63u;
       const unsigned long long m_halt = __builtin_amdgcn_ballot_w64(!may_go_on);      // (flags do not change in a pass)
+      TailK K;
+      K.halfpi = sconst(MCS_PIO2_DD_0); K.pio2_lo = sconst(MCS_PIO2_DD_1); K.twopi = sconst(MCS_TWOPI_DD_0); K.twopi_lo = sconst(MCS_TWOPI_DD_1);
+      K.inv_twopi = sconst(MCS_INV_TWOPI); K.sin_ul = sconst(0x1.fffffffffffffp-1); K.dmin = sconst(2.2250738585072014e-308);
 #pragma nounroll
       for (;;) {
         PROF_LANES(9, active); PROF_ADD(7, 1);
@@ -2211,13 +2271,13 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         if (!h.dont_scatter) {
           rng.n += 2u;
           const double cos_d = S_evf[wv][0][128u + e], sin_d = S_evf[wv][1][128u + e], c_ps = S_evf[wv][2][128u + e], ssd = S_evf[wv][6][128u + e];
-          scattering_rest(p, kc, cos_d, sin_d, c_ps, ssd);
+          scattering_rest_k(p, kc, K, cos_d, sin_d, c_ps, ssd);
         }
         p.acctime = p.acctime + t_clock * p.c_gef;
         p.n_ovr += (unsigned)p.ovr_inc;
         const bool ev_time = p.acctime >= p.c_tev;
         bool x1;
-        const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1, true) | ev_time | (p.helix >= MCS_HELIX_CAP);
+        const bool e1 = move_and_detect_thr(a, h, p, phi_prev, x1, true, &K) | ev_time | (p.helix >= MCS_HELIX_CAP);
         evw = (e1 ? 5 : 4) | (x1 ? 2 : 0);
         e = (e + 1u) & 63u; jj += 1u;
         t_clock = p.t_step;
