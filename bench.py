@@ -181,7 +181,7 @@ def main():
                     help="what the host fetches at every species end: the 0.8 MB it computes with (light) or the whole 61 MB buffer (full)")
     ap.add_argument("--overlap", type=int, default=3,
                     help="extra leg, reported beside `value` and never in it: this many independent iterations in flight (driver.run_overlapped); 1 = skip")
-    ap.add_argument("--long-draws", type=int, default=8192,
+    ap.add_argument("--long-draws", type=int, default=6144,
                     help="extra leg at N=1 (not the headline): the pcuts pipelined, long histories = this many random draws (0: skip)")
     ap.add_argument("--smooth", action="store_true", help="replace the shock profile after every iteration (smooth_grid_par): config[2]'s loop")
     ap.add_argument("--mixed", action="store_true", help="BASELINE config[4]'s species mix: protons + He + electrons, radiative losses, ion -> electron energy transfer (--particles per species)")

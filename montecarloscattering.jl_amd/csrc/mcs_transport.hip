@@ -57,6 +57,9 @@
 #define MCS_PASSES_PER_ITER 6     // common passes per trip through the loop header (see the end of the loop)
 #endif
 #ifndef MCS_MERGE_POLL_MASK
+#ifndef MCS_TAIL_CROSS
+#define MCS_TAIL_CROSS 1
+#endif
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
 #endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
@@ -2283,6 +2286,29 @@ __device__ __forceinline__ void transport_body(const KArgs* __restrict__ ka) {
         t_clock = p.t_step;
         const unsigned long long m_stop = __builtin_amdgcn_ballot_w64(e1 | x1 | (jj >= ringD)) | m_halt;
         if ((m_stop & am_t) != 0ull) break;
+      }
+      // ---- why the loop ended is, most of the time, a zone crossing with nothing else going on.  What the rare region does for such a
+      // lane (see `full` and plain_crossing there: the same expressions on the same state) is done HERE, behind the loop: the lane comes
+      // to the next loop header with nothing pending, and the trip skips the region (its skeleton is ~1 500 cycles for a wave alone on
+      // its SIMD).  Anything else -- a time event, the cap, an upward threshold, the fine / coarse switch, the upstream boundary, a
+      // crossing that plain_crossing refuses -- is left as the pass left it: the region derives what is due from that state, as always.
+      // (The register mirror of the stack height lags this trip's pushes: brought up to date first, as the header would.)
+      if (MCS_TAIL_CROSS) {
+        ev_pending += (unsigned)(__popcll(__builtin_amdgcn_ballot_w64(p.npush > 0)) + __popcll(__builtin_amdgcn_ballot_w64(p.npush > 1)));
+        p.npush = 0;
+        if (ev_pending < 64u) {
+          if (active & ((evw & 3) == 2) & (p.flags == 0) & !(h.etf | h.odd_cfg | h.custom_epsB | h.every_pass)) {
+            const bool fwd = p.x > p.x_old;
+            const bool same_zone = (fwd & (p.z_hi > p.x)) | (!fwd & (p.z_lo <= p.x));
+            const bool ev_up = ((p.x >= h.x_grid_stop) & ((p.x_old < h.x_grid_stop) | ((p.x_old < p.prp) & (p.x >= p.prp)))) | (p.x > p.x_dt);
+            const bool ev_xn = (p.x > p.gyro_rad_tot) != (p.xn_per == h.xn_coarse);
+            const bool feb_due = (p.i_grid <= h.i_grid_feb) & p.inj & (p.x < h.feb_up);
+            if (!(ev_up | ev_xn | feb_due)) {
+              const bool handled = same_zone ? true : plain_crossing(a, h, p, ev_pending);      // (same zone: a threshold reached with nothing due)
+              if (handled) { refresh_thr<false>(h, p); evw = 4; }
+            }
+          }
+        }
       }
     } else
 #pragma unroll
