@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile at HEAD: rocprofv3 kernel-trace stats of the bench command plus separate --pmc passes (HBM traffic, SQ
-# counters), for the headline size and for 1e7 particles.  usage (on the GPU box): tools/profile_round.sh <tag>
+# counters), for the headline size and for 1e7 particles.  usage (on the GPU box): tools/profile_round.sh <tag> [only1e6]
 # -> gpurun_out/<tag>/summary_1e6.txt, summary_1e7.txt, traffic.json (copied to profiles/ by hand)
 set -e
 TAG=$1; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -51,4 +51,4 @@ for name in ("stats", "sq"):
 PY
 }
 run_passes 1e6 --steps 2 --warmup 1
-run_passes 1e7 --particles 10000000 --steps 1 --warmup 0
+if [ "$2" != "only1e6" ]; then run_passes 1e7 --particles 10000000 --steps 1 --warmup 0; fi
