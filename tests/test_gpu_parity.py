@@ -516,6 +516,45 @@ def test_wave_specialised_kernel_is_bit_identical(monkeypatch, case, N):
     assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
 
 
+@pytest.mark.parametrize("case,N", [("plain", 6000), ("general", 6000), ("plain_etf", 4000), ("plain", 40)])
+def test_tail_loop_is_bit_identical(monkeypatch, case, N):
+    """Once a launch's queue has run dry, a wave with at most MCS_TAIL_LOOP (12) live particles runs its passes in a loop of their own
+    (transport_body "tail loop": the draw-dependent half from the tail ring, the state-dependent half with its literals in scalar
+    registers, one exit test; a plain zone crossing that ended the loop handled right behind it) instead of the six-pass trip of the
+    bulk.  Same statements on the same values in the same order: every particle, saved array and integer tally must equal those of
+    MCS_TAIL_LOOP=0 -- which the other tests of this file ran against the oracle until the loop existed, as they now run the loop
+    against it.  Sizes: a few blocks that reach the tail at once (6000, 4000), less than one wave (40: in the loop from the start);
+    the PLAIN kernel, the general one (MCS_FORCE_GENERAL=1) and the ions' kernel of a species mix."""
+    kw = {} if case != "plain_etf" else dict(species=[mcs.inputs.Species(1.0, 1.0, 1e6, 1.0), mcs.inputs.Species(4.0, 2.0, 1e6, 0.1)],
+                                             energy_transfer_frac=0.1, radiation_losses=True)
+    prob = make_problem(N, **kw)
+    monkeypatch.setenv("MCS_FORCE_GENERAL", "1" if case == "general" else "0")
+    out = []
+    for tl in ("12", "0"):
+        monkeypatch.setenv("MCS_TAIL_LOOP", tl)
+        hb = hip_backend(prob)
+        start_species(hb, prob)
+        fin = []
+        for ip in range(1, 12):
+            n = hb.pop_size()
+            ns = hb.run_pcut(ip, 0)
+            fin.append((hb.finals(), hb.get_saved()))
+            if ns == 0: break
+            hb.new_pcut(max(n // ns, 1))
+        out.append((fin, hb.read_tallies()))
+        assert hb.last_kernel() == {"plain": 1, "general": 0, "plain_etf": 6}[case]
+        hb.destroy()
+    (fa, (Ta, Ia)), (fb, (Tb, Ib)) = out
+    assert len(fa) == len(fb)
+    for (xa, (sa, la)), (xb, (sb, lb)) in zip(fa, fb):
+        for k in xa:
+            assert np.array_equal(bits(xa[k]), bits(xb[k])), k
+        assert np.array_equal(la, lb)
+        assert_pop_equal(sa, sb, "saved arrays, tail loop on vs off")
+    assert np.array_equal(Ia, Ib)
+    assert_tallies_close(mcs.capi.Layout(prob.params), Ta, Tb, TALLY_RTOL)
+
+
 def test_wave_specialised_kernel_is_picked_by_population_size(monkeypatch):
     """Without MCS_K1_WS the library picks the wave-specialised kernel for launches of at least MCS_WS_AUTO_MIN particles (6e6: it is
     level with the lane-owns-particle kernel at 4e6 and 3.8 % faster at 1e7, profiles/r04_ws_kernel_ab.txt) and the lane-owns-particle
