@@ -57,10 +57,10 @@
 #define MCS_PASSES_PER_ITER 6     // common passes per trip through the loop header (see the end of the loop)
 #endif
 #ifndef MCS_MERGE_POLL_MASK
-#ifndef MCS_TAIL_CROSS
-#define MCS_TAIL_CROSS 1
-#endif
 #define MCS_MERGE_POLL_MASK 15u   // tail consolidation: the waves of a pair look at each other every 16 passes
+#endif
+#ifndef MCS_TAIL_CROSS
+#define MCS_TAIL_CROSS 1          // tail loop: a plain zone crossing that ended the loop is handled right behind it (0: A/B builds)
 #endif
 // Rare paths (zone-crossing tallies, frame transforms, retro walk, finish): outlined
 // calls with by-value arguments, or inlined (-DMCS_INLINE_COLD) -- a tuning knob.
