@@ -30,8 +30,7 @@ LIMITS = {
     "mcs_k_transport_ws_etf": dict(vgprs=256, vgpr_spill=24, scratch=76, occupancy=2, lds=131072),
     # round 4: the retro walk is inlined in the fp32 kernels -- the 192-208 B/lane of rounds 2-3 were the frame of that one call
     # (the 34-word lane state and the RNG stream passed by reference), not spills
-    # (+ the tail loop of the organised fp32 kernel: 100 B)
-    "mcs_k_transport_f32": dict(vgprs=168, vgpr_spill=32, scratch=104, occupancy=3, lds=54613),
+    "mcs_k_transport_f32": dict(vgprs=168, vgpr_spill=32, scratch=96, occupancy=3, lds=54613),
     "mcs_k_transport_f32_lossy": dict(vgprs=168, vgpr_spill=32, scratch=96, occupancy=3, lds=54613),
     "mcs_k_transport_f32_loop": dict(vgprs=168, vgpr_spill=0, scratch=0, occupancy=3, lds=40960),
     "mcs_k_transport_f32_loop_exact": dict(vgprs=168, vgpr_spill=0, scratch=16, occupancy=3, lds=40960),
